@@ -1,0 +1,77 @@
+"""Pin the CPU oracle against fixtures produced by the reference module itself
+(tests/golden/make_golden.py; reference restormer_arch.py:245-284 and demo.py:120-161)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ira_amd.config import RestormerConfig
+from ira_amd.weights import seeded_state_dict, to_torch
+from oracle import restormer_oracle as O
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    cfg = RestormerConfig(**json.loads(str(z['cfg'])))
+    return z, cfg
+
+
+NET = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'net_*.npz')))
+HARNESS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'harness_*.npz')))
+
+
+def test_fixtures_present():
+    assert len(NET) >= 6 and len(HARNESS) >= 6
+
+
+@pytest.mark.parametrize('path', NET, ids=[os.path.basename(p)[4:-4] for p in NET])
+def test_network_matches_reference(path):
+    if '128' in path:
+        torch.set_num_threads(8)
+    z, cfg = _load(path)
+    sd = to_torch(seeded_state_dict(cfg, int(z['seed'])))
+    with torch.no_grad():
+        y = O.restormer_forward(torch.from_numpy(z['input']), sd, cfg.to_dict()).numpy()
+    ref = z['output']
+    # same fp32 ops in a slightly different association: round-off only
+    assert y.shape == ref.shape
+    assert np.max(np.abs(y - ref)) < 2e-5, np.max(np.abs(y - ref))
+
+
+@pytest.mark.parametrize('path', HARNESS, ids=[os.path.basename(p)[8:-4] for p in HARNESS])
+def test_harness_matches_reference(path):
+    z, cfg = _load(path)
+    sd = to_torch(seeded_state_dict(cfg, int(z['seed'])))
+    tile = int(z['tile'])
+    out = O.restore_image(z['noisy'], sd, cfg.to_dict(), tile=None if tile < 0 else tile,
+                          tile_overlap=int(z['overlap']))
+    ref = z['restored']
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    # uint8 outputs: identical except where fp32 round-off straddles a rounding boundary
+    assert diff.max() <= 1
+    assert (diff != 0).mean() < 1e-3
+    assert abs(O.psnr_u8(out, z['clean']) - O.psnr_u8(ref, z['clean'])) < 1e-3
+
+
+def test_tile_index_list_4k():
+    # 3840x2160, tile 512, overlap 32 -> 5 x 8 = 40 tiles
+    rows = O.tile_index_list(2160, 512, 480)
+    cols = O.tile_index_list(3840, 512, 480)
+    assert rows == [0, 480, 960, 1440, 1648]
+    assert cols == [0, 480, 960, 1440, 1920, 2400, 2880, 3328]
+
+
+def test_pad_amounts_quirk():
+    # demo.py:123-126: H=((h+8)//8)*8 but only applied when h%8 != 0
+    assert O.pad_amounts(64, 88) == (0, 0)
+    assert O.pad_amounts(75, 91) == (5, 5)
+    assert O.pad_amounts(1, 9) == (7, 7)
+
+
+def test_img_as_ubyte_half_even():
+    x = np.array([0.5 / 255, 1.5 / 255, 2.5 / 255, 1.0, 0.0], dtype=np.float32)
+    assert O.img_as_ubyte(x).tolist() == [0, 2, 2, 255, 0]
