@@ -1,0 +1,49 @@
+// Launchers of the hand-written gfx950 kernels (ira_kernels.hip). Host-side C++ interface used by
+// ira_runtime.hip; the public boundary is include/ira.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ira {
+
+// All launchers enqueue on `st` and return hipGetLastError(). T = tiles, P = pixels per tile.
+
+hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K,
+                          const void* W, const float* bias, void* y, int y_stride, int n_store,
+                          int NB, int T, int P);
+
+hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
+                          const void* W, long w_tile_stride, const float* bias, const float* resid,
+                          float* y, int N, int NB, int T, int P);
+
+hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias,
+                             void* qk, void* v, int T, int H, int W, int C);
+
+hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, const float* bias,
+                              void* out, int T, int H, int W, int Hp);
+
+hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int nblk, int C, int heads, int S);
+
+hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
+                           void* M, int T, int C, int heads, int S, int NB);
+
+hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
+                          const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);
+
+hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out,
+                        int T, int H, int W, int ic, int C);
+
+hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx);
+
+// tiler
+hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int w, int c, int Hp, int Wp,
+                                int th, int tw, int stride_h, int stride_w, int n_rows, int n_cols,
+                                int first_tile, int n_tiles, float* tiles);
+
+hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c, int Hp, int Wp, int th, int tw,
+                        int stride_h, int stride_w, int n_rows, int n_cols, uint8_t* out);
+
+hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
+hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
+
+}  // namespace ira

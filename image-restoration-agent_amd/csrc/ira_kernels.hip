@@ -1,0 +1,838 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the Restormer hot path.
+//
+// Reference being re-implemented (never copied): restormer_arch.py:19-284 and demo.py:120-161 of
+// AgenticIR/executor/defocus_deblurring/tools/Restormer/.  Layouts and the numerics contract are in
+// DESIGN.md.  Short version:
+//   residual stream x      fp32 NHWC  [T][H][W][C]
+//   branch activations     fp16 NHWC  (qkv_pre, v, hidden_pre, gated hidden)
+//   q,k after the dwconv   fp16 "pixel-minor" [T][H][ceil(W/8)][2C][8]   (K-dim of the Gram = pixels)
+//   all contractions       v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fp32 accumulate
+//   LN statistics, dwconv, softmax, GELU, residual adds: fp32 VALU
+//
+// MFMA operand convention used by every 1x1 / 3x3 conv here ("weights are A, pixels are B"):
+//   D[32 ch][32 px] += A[32 ch][16 k] * B[16 k][32 px]
+//   lane l: r = l & 31, h = l >> 5.
+//   B fragment of lane (r,h): 8 consecutive input channels 16s+8h .. +7 of pixel r   (one 16-byte load, NHWC)
+//   A fragment of lane (r,h): W[row 32nb + rowperm(r)][16s+8h .. +7]                 (one 16-byte load, [N][K])
+//   D: lane (r,h), register t holds MFMA row (t&3) + 8(t>>2) + 4h.  With rowperm() below that row is
+//      output channel 32nb + 16(t>>3) + 8h + (t&7): each lane owns two runs of 8 consecutive
+//      channels of ITS pixel -> 16/32-byte NHWC stores, and the registers are already the B fragment
+//      (k = 16s + 8h + j) of a following MFMA that contracts over these channels.
+#include "ira_kernels.h"
+
+namespace ira {
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IRA_DEV __device__ __forceinline__
+
+IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
+
+IRA_DEV half8 cvt8(const f32x4 lo, const f32x4 hi) {
+    half8 o;
+    o[0] = (f16)lo[0]; o[1] = (f16)lo[1]; o[2] = (f16)lo[2]; o[3] = (f16)lo[3];
+    o[4] = (f16)hi[0]; o[5] = (f16)hi[1]; o[6] = (f16)hi[2]; o[7] = (f16)hi[3];
+    return o;
+}
+
+IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; return z; }
+
+IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
+
+IRA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1) conv, "K-resident": all K input channels of the wave's 32 pixels stay in
+// registers (optionally LayerNorm-ed there), the wave loops over 32-row blocks of W.
+// Used for LN + qkv 1x1 (restormer_arch.py:105,114 after :146) and LN + project_in (:82,89).
+//   x: [T*P][K] fp32 or fp16.   W: [NB*32][K] fp16 (rows >= N zero).   y: [T*P][y_stride] fp16.
+// LN: 0 none; 1 BiasFree core x*rsqrt(var+1e-5) (:37-39); 2 WithBias core (x-mu)*rsqrt(var+1e-5)
+// (:54-57). The gain (and W@ln_bias) are folded into W / bias by the packer.
+template <int KS, int LN, bool IN_F32>
+__global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, const f16* __restrict__ W,
+                                                 const float* __restrict__ bias, f16* __restrict__ y,
+                                                 int y_stride, int n_store, int NB, int T, int P) {
+    constexpr int K = KS * 16;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int chunks = (P + 31) >> 5;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long)T * chunks) return;
+    const int t = (int)(wv / chunks);
+    const int p = (int)(wv % chunks) * 32 + r;
+    const bool valid = p < P;
+    const long px = (long)t * P + (valid ? p : P - 1);
+
+    half8 b[KS];
+    if constexpr (IN_F32) {
+        const float* src = (const float*)xin + px * K + 8 * h;
+        float xv[KS][8];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 lo = *(const f32x4*)(src + 16 * s);
+            const f32x4 hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+        }
+        if constexpr (LN != 0) {
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += xv[s][j];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / K);
+            float sq = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f);
+            const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[s][j] = (xv[s][j] - sub) * rstd;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[s][j] = (f16)xv[s][j];
+    } else {
+        const f16* src = (const f16*)xin + px * K + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = *(const half8*)(src + 16 * s);
+    }
+
+    const f16* wrow = W + (long)rowperm(r) * K + 8 * h;
+    f16* dst = y + px * y_stride + 8 * h;
+    for (int nb = 0; nb < NB; ++nb) {
+        f32x16 acc;
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[8 * u + j] = bias[32 * nb + 16 * u + 8 * h + j];
+        } else {
+            acc = zero16();
+        }
+        const f16* wp = wrow + (long)nb * 32 * K;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const half8 a = *(const half8*)(wp + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * nb + 16 * u + 8 * h;
+            if (valid && n0 + 8 <= n_store) {
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)acc[8 * u + j];
+                *(half8*)(dst + 32 * nb + 16 * u) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1) conv, "N-resident": fp32 accumulators for all N output channels of the wave's 32
+// pixels stay in registers; the wave streams over K (one or two concatenated sources).  fp32 out with
+// optional residual add.  Used for attention apply (per-tile matrix M on V) + residual, project_out
+// + residual (restormer_arch.py:92,131,148-149), reduce_chan on cat([up, skip]) (:260-261,265-266).
+template <int NB, bool IN_F32>
+__global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, int K0,
+                                                 const void* __restrict__ x1, int K1,
+                                                 const f16* __restrict__ W, long w_tile_stride,
+                                                 const float* __restrict__ bias,
+                                                 const float* resid, float* y,   // may alias (x += ...)
+                                                 int N, int T, int P) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int chunks = (P + 31) >> 5;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long)T * chunks) return;
+    const int t = (int)(wv / chunks);
+    const int p = (int)(wv % chunks) * 32 + r;
+    const bool valid = p < P;
+    const long px = (long)t * P + (valid ? p : P - 1);
+    const int K = K0 + K1;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * nb + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        } else {
+            acc[nb] = zero16();
+        }
+    }
+
+    const f16* wrow = W + (long)t * w_tile_stride + (long)rowperm(r) * K + 8 * h;
+    const int KT = K >> 4;
+    for (int s = 0; s < KT; ++s) {
+        const int c0 = 16 * s;
+        half8 b;
+        if constexpr (IN_F32) {
+            const float* src = (c0 < K0) ? ((const float*)x0 + px * K0 + c0 + 8 * h)
+                                         : ((const float*)x1 + px * K1 + (c0 - K0) + 8 * h);
+            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else {
+            const f16* src = (c0 < K0) ? ((const f16*)x0 + px * K0 + c0 + 8 * h)
+                                       : ((const f16*)x1 + px * K1 + (c0 - K0) + 8 * h);
+            b = *(const half8*)src;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const half8 a = *(const half8*)(wrow + (long)nb * 32 * K + c0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+        }
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * nb + 16 * u + 8 * h;
+            if (n0 + 8 <= N) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
+                if (resid != nullptr) {
+                    const f32x4 rl = *(const f32x4*)(resid + px * N + n0);
+                    const f32x4 rh = *(const f32x4*)(resid + px * N + n0 + 4);
+                    lo += rl; hi += rh;
+                }
+                *(f32x4*)(y + px * N + n0) = lo;
+                *(f32x4*)(y + px * N + n0 + 4) = hi;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 3x3, zero padding (restormer_arch.py:84,106).  One thread = 8 consecutive pixels of one
+// image row x 8 channels (an 8x8 register block): 3 rows x 10 input vectors (16 B each) per block.
+//   in: fp16 NHWC [T][H][W][Cs];  w: fp32 [9][Cs] (tap-major), bias fp32 [Cs] or null.
+// MODE 0 (qkv, Cs = 3C): channel groups of q,k -> pixel-minor [T][H][WB][2C][8] (rows padded with
+//         zeros to WB*8 pixels so the Gram ignores them); v -> NHWC [T][H][W][C].
+// MODE 1 (GDFN gate, Cs = 2*Hp): out[T][H][W][Hp] = gelu(dw(in[.., :Hp])) * dw(in[.., Hp:]) (:90-91).
+template <int MODE>
+__device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float* __restrict__ w,
+                                         const float* __restrict__ bias, int H, int W, int Cs, int t,
+                                         int y, int x0, int ch0, float (&acc)[8][8]) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= H) continue;
+        const f16* rowp = in + ((long)(t * H + yy) * W) * Cs + ch0;
+        half8 v[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int xx = x0 - 1 + i;
+            v[i] = (xx >= 0 && xx < W) ? *(const half8*)(rowp + (long)xx * Cs) : zero8();
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
+            const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
+            float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[p + dx][e], wv[e], acc[p][e]);
+        }
+    }
+    if (bias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float bv = bias[ch0 + e];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p][e] += bv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, f16* __restrict__ qk,
+                                                    f16* __restrict__ v, int T, int H, int W, int C) {
+    const int WB = (W + 7) >> 3, G = (3 * C) >> 3, GQK = (2 * C) >> 3;
+    const long total = (long)T * H * WB * G;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    long rest = idx / G;
+    const int xb = (int)(rest % WB); rest /= WB;
+    const int y = (int)(rest % H);
+    const int t = (int)(rest / H);
+    const int x0 = xb * 8;
+    float acc[8][8];
+    dw_block<0>(in, w, bias, H, W, 3 * C, t, y, x0, g * 8, acc);
+    if (g < GQK) {
+        f16* dst = qk + ((((long)(t * H + y) * WB + xb) * (2 * C)) + g * 8) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            half8 o;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) o[p] = (x0 + p < W) ? (f16)acc[p][e] : (f16)0.f;
+            *(half8*)(dst + e * 8) = o;
+        }
+    } else {
+        f16* dst = v + ((long)(t * H + y) * W + x0) * C + (g - GQK) * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (x0 + p < W) {
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)acc[p][e];
+                *(half8*)(dst + (long)p * C) = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, f16* __restrict__ out,
+                                                     int T, int H, int W, int Hp) {
+    const int WB = (W + 7) >> 3, G = Hp >> 3;
+    const long total = (long)T * H * WB * G;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    long rest = idx / G;
+    const int xb = (int)(rest % WB); rest /= WB;
+    const int y = (int)(rest % H);
+    const int t = (int)(rest / H);
+    const int x0 = xb * 8;
+    float a1[8][8], a2[8][8];
+    dw_block<1>(in, w, bias, H, W, 2 * Hp, t, y, x0, g * 8, a1);
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a1[p][e] = gelu_erf(a1[p][e]);
+    dw_block<1>(in, w, bias, H, W, 2 * Hp, t, y, x0, Hp + g * 8, a2);
+    f16* dst = out + ((long)(t * H + y) * W + x0) * Hp + g * 8;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (x0 + p < W) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(a1[p][e] * a2[p][e]);
+            *(half8*)(dst + (long)p * Hp) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Partial Gram q k^T and squared norms over pixels (restormer_arch.py:121-124), K-dim = pixels.
+// qk: pixel-minor fp16 [T][nblk][2C][8]: for every channel 8 consecutive pixels are one 16-byte vector,
+// which is exactly the A/B fragment of v_mfma_f32_16x16x32_f16 (lane l: row/col l&15, k = 8(l>>4)+j).
+// One wave = (tile, head, split s): strides over the tile's 32-pixel steps s, s+S, ...
+// part: fp32 [T][S][heads][c*c + 2c]: gram[qi][kj], then sum q^2 [c], then sum k^2 [c].
+template <int CT>
+__global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float* __restrict__ part, int T,
+                                              int nblk, int C, int heads, int S) {
+    constexpr int c = CT * 16;
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long)T * heads * S) return;
+    const int s = (int)(wv % S);
+    const int hd = (int)((wv / S) % heads);
+    const int t = (int)(wv / ((long)S * heads));
+
+    f32x4 acc[CT][CT];
+    float nq[CT], nk[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        nq[i] = 0.f; nk[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nsteps = (nblk + 3) >> 2;
+    const f16* base = qk + (long)t * nblk * (2 * C) * 8;
+    for (int step = s; step < nsteps; step += S) {
+        const int blk = step * 4 + lg;
+        const bool ok = blk < nblk;
+        const f16* bp = base + ((long)(ok ? blk : 0) * (2 * C) + hd * c + li) * 8;
+        half8 a[CT], b[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            a[i] = ok ? *(const half8*)(bp + (long)(16 * i) * 8) : zero8();
+            b[i] = ok ? *(const half8*)(bp + (long)(C + 16 * i) * 8) : zero8();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float qa = (float)a[i][j], kb = (float)b[i][j];
+                nq[i] = fmaf(qa, qa, nq[i]);
+                nk[i] = fmaf(kb, kb, nk[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float* dst = part + (((long)t * S + s) * heads + hd) * (c * c + 2 * c);
+    // D layout 16x16: col = lane & 15 (k channel), row = 4*(lane>>4) + reg (q channel)
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(16 * i + 4 * lg + e) * c + 16 * j + li] = acc[i][j][e];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        float a = nq[i], b = nk[i];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (lg == 0) {
+            dst[c * c + 16 * i + li] = a;
+            dst[c * c + c + 16 * i + li] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per (tile, head): reduce the S partial Grams in fixed order (bitwise reproducible), cosine-normalise
+// (F.normalize eps 1e-12), * temperature, softmax over the key channel (restormer_arch.py:121-125),
+// then fold project_out (:131):  M[o][hd*c + j] = sum_i Wo[o][hd*c + i] * attn[i][j]   so that
+// project_out(attn @ v) == conv1x1(v, M).  M: fp16 [T][NB*32][C], rows >= C are never touched (zeroed
+// once at allocation).
+__global__ __launch_bounds__(256) void k_attn_mix(const float* __restrict__ part, const float* __restrict__ wo,
+                                                  const float* __restrict__ temp, f16* __restrict__ M, int T,
+                                                  int C, int heads, int S, int NB) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = C / heads;
+    const int hd = blockIdx.x % heads, t = blockIdx.x / heads;
+    const int tid = threadIdx.x;
+    float* G = sm;                 // [c][c]
+    float* nq = sm + c * c;        // [c]
+    float* nk = nq + c;            // [c]
+    const int rec = c * c + 2 * c;
+    for (int idx = tid; idx < rec; idx += blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[(((long)t * S + s) * heads + hd) * rec + idx];
+        sm[idx] = a;
+    }
+    __syncthreads();
+    const float tmp = temp[hd];
+    for (int i = tid; i < c; i += blockDim.x) {
+        const float qn = fmaxf(sqrtf(nq[i]), 1e-12f);
+        float mx = -INFINITY;
+        for (int j = 0; j < c; ++j) {
+            const float kn = fmaxf(sqrtf(nk[j]), 1e-12f);
+            const float l = G[i * c + j] / (qn * kn) * tmp;
+            G[i * c + j] = l;
+            mx = fmaxf(mx, l);
+        }
+        float den = 0.f;
+        for (int j = 0; j < c; ++j) { const float e = expf(G[i * c + j] - mx); G[i * c + j] = e; den += e; }
+        const float inv = 1.0f / den;
+        for (int j = 0; j < c; ++j) G[i * c + j] *= inv;
+    }
+    __syncthreads();
+    f16* Mt = M + (long)t * NB * 32 * C;
+    for (int idx = tid; idx < C * c; idx += blockDim.x) {
+        const int o = idx / c, j = idx % c;
+        const float* wr = wo + (long)o * C + hd * c;
+        float a = 0.f;
+        for (int i = 0; i < c; ++i) a = fmaf(wr[i], G[i * c + j], a);
+        Mt[(long)o * C + hd * c + j] = (f16)a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense 3x3 conv, zero padding, as 9 shifted 1x1 MFMA contractions (implicit GEMM):
+// OverlapPatchEmbed is k_embed below; this one serves Downsample / Upsample / output
+// (restormer_arch.py:171-189,243,281).   in fp32 NHWC [T][H][Wd][K]; W fp16 [9][NBtot*32][K]; out fp32.
+// MODE 0 plain [T][H][Wd][N]; 1 PixelUnshuffle(2) -> [T][H/2][Wd/2][4N]; 2 PixelShuffle(2) ->
+// [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281).
+template <int NBW, int MODE>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const f16* __restrict__ W,
+                                                 const float* __restrict__ bias, const float* __restrict__ skip,
+                                                 float* __restrict__ out, int T, int H, int Wd, int K, int N,
+                                                 int NBtot) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int P = H * Wd;
+    const int chunks = (P + 31) >> 5;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long)T * chunks) return;
+    const int nb0 = blockIdx.y * NBW;
+    const int t = (int)(wv / chunks);
+    const int p = (int)(wv % chunks) * 32 + r;
+    const bool valid = p < P;
+    const int pc = valid ? p : P - 1;
+    const int y = pc / Wd, x = pc % Wd;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        } else {
+            acc[nb] = zero16();
+        }
+    }
+    const int KT = K >> 4;
+    const f16* wbase = W + (long)rowperm(r) * K + 8 * h;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+        const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
+        const f16* wt = wbase + (long)tap * NBtot * 32 * K;
+        for (int s = 0; s < KT; ++s) {
+            half8 b = cvt8(*(const f32x4*)(src + 16 * s), *(const f32x4*)(src + 16 * s + 4));
+            if (!inb) b = zero8();
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                if (nb0 + nb < NBtot) {
+                    const half8 a = *(const half8*)(wt + (long)(nb0 + nb) * 32 * K + 16 * s);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                if (n >= N) continue;
+                const float val = acc[nb][8 * u + j];
+                if constexpr (MODE == 0) {
+                    out[((long)t * P + p) * N + n] = val;
+                } else if constexpr (MODE == 1) {
+                    const int oc = n * 4 + (y & 1) * 2 + (x & 1);
+                    out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
+                } else if constexpr (MODE == 2) {
+                    const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                } else {
+                    const long o = ((long)t * P + p) * N + n;
+                    out[o] = val + skip[o];
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// OverlapPatchEmbed (restormer_arch.py:156-165): 3x3 conv from 1/3 input channels, fp32 VALU (exact
+// fp32 like the reference; 0.1% of the FLOPs).  One thread = one pixel x 8 output channels.
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, const float* __restrict__ w,
+                                               const float* __restrict__ bias, float* __restrict__ out, int T,
+                                               int H, int W, int ic, int C) {
+    const int G = C >> 3;
+    const long total = (long)T * H * W * G;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const long px = idx / G;
+    const int x = (int)(px % W);
+    const int y = (int)((px / W) % H);
+    const int t = (int)(px / ((long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[g * 8 + e] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1;
+            if (xx < 0 || xx >= W) continue;
+            const float* src = in + ((long)(t * H + yy) * W + xx) * ic;
+            for (int ci = 0; ci < ic; ++ci) {
+                const float v = src[ci];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] = fmaf(v, w[((long)(g * 8 + e) * ic + ci) * 9 + ky * 3 + kx], acc[e]);
+            }
+        }
+    }
+    float* dst = out + px * C + g * 8;
+    *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+__global__ __launch_bounds__(256) void k_concat2(const float* __restrict__ a, int Ca, const float* __restrict__ b,
+                                                 int Cb, float* __restrict__ out, long npx) {
+    const int Cv = (Ca + Cb) >> 2;   // float4 per pixel
+    const long total = npx * Cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long px = idx / Cv;
+        const int cv = (int)(idx % Cv) * 4;
+        const f32x4 v = (cv < Ca) ? *(const f32x4*)(a + px * Ca + cv) : *(const f32x4*)(b + px * Cb + (cv - Ca));
+        *(f32x4*)(out + px * (Ca + Cb) + cv) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiler (demo.py:120-153).
+IRA_DEV int tile_origin(int i, int n, int stride, int full, int tile) { return (i == n - 1) ? (full - tile) : i * stride; }
+
+// uint8 HWC frame -> float32 NHWC tiles:  x/255 (demo.py:120), reflect pad to (Hp,Wp) (demo.py:127),
+// crop tile (demo.py:147).
+__global__ __launch_bounds__(256) void k_extract_tiles(const uint8_t* __restrict__ frame, int h, int w, int c,
+                                                       int Hp, int Wp, int th, int tw, int stride_h, int stride_w,
+                                                       int n_rows, int n_cols, int first_tile, int n_tiles,
+                                                       float* __restrict__ tiles) {
+    const long total = (long)n_tiles * th * tw * c;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        long rest = idx / c;
+        const int xx = (int)(rest % tw); rest /= tw;
+        const int yy = (int)(rest % th);
+        const int tl = (int)(rest / th) + first_tile;
+        const int ri = tl / n_cols, ci = tl % n_cols;
+        int Y = tile_origin(ri, n_rows, stride_h, Hp, th) + yy;
+        int X = tile_origin(ci, n_cols, stride_w, Wp, tw) + xx;
+        if (Y >= h) Y = 2 * (h - 1) - Y;     // F.pad(..., 'reflect') on the bottom / right edge
+        if (X >= w) X = 2 * (w - 1) - X;
+        tiles[idx] = __fdiv_rn((float)frame[((long)Y * w + X) * c + ch], 255.0f);
+    }
+}
+
+// E += tile, W += 1 in row-major tile order; E/W; clamp; crop; rint(x*255) (demo.py:145-161).
+__global__ __launch_bounds__(256) void k_blend(const float* __restrict__ tiles, int h, int w, int c, int Hp, int Wp,
+                                               int th, int tw, int stride_h, int stride_w, int n_rows, int n_cols,
+                                               uint8_t* __restrict__ out) {
+    const long total = (long)h * w * c;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int x = (int)((idx / c) % w);
+        const int y = (int)(idx / ((long)c * w));
+        float E = 0.f, Wt = 0.f;
+        for (int ri = 0; ri < n_rows; ++ri) {
+            const int y0 = tile_origin(ri, n_rows, stride_h, Hp, th);
+            if (y < y0 || y >= y0 + th) continue;
+            for (int ci = 0; ci < n_cols; ++ci) {
+                const int x0 = tile_origin(ci, n_cols, stride_w, Wp, tw);
+                if (x < x0 || x >= x0 + tw) continue;
+                const long tl = (long)ri * n_cols + ci;
+                E += tiles[((tl * th + (y - y0)) * tw + (x - x0)) * c + ch];
+                Wt += 1.0f;
+            }
+        }
+        float v = __fdiv_rn(E, Wt);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        out[idx] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                      int C, int H, int W) {
+    const long total = (long)B * C * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % C);
+        const long px = idx / C;
+        const long hw = px % ((long)H * W);
+        const long b = px / ((long)H * W);
+        out[idx] = in[(b * C + ch) * (long)H * W + hw];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                      int C, int H, int W) {
+    const long total = (long)B * C * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long hw = idx % ((long)H * W);
+        const int ch = (int)((idx / ((long)H * W)) % C);
+        const long b = idx / ((long)C * H * W);
+        out[idx] = in[(b * (long)H * W + hw) * C + ch];
+    }
+}
+
+// =============================================================================================
+// launchers
+static inline unsigned grid1d(long total, int block, long cap = 1L << 30) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+template <int KS>
+static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
+                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P) {
+    const long waves = (long)T * ((P + 31) / 32);
+    const dim3 grid(grid1d(waves, 4)), block(256);
+#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P)
+    if (in_f32) {
+        if (ln == 0) IRA_KRES(0, true); else if (ln == 1) IRA_KRES(1, true); else IRA_KRES(2, true);
+    } else {
+        if (ln != 0) return hipErrorInvalidValue;
+        IRA_KRES(0, false);
+    }
+#undef IRA_KRES
+    return hipGetLastError();
+}
+
+hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
+                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P) {
+    if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
+    const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
+    switch (K / 16) {
+#define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P);
+        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(8) IRA_CASE(12) IRA_CASE(24)
+#undef IRA_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NB>
+static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
+                                   const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
+                                   int T, int P) {
+    const long waves = (long)T * ((P + 31) / 32);
+    const dim3 grid(grid1d(waves, 4)), block(256);
+    if (in_f32) hipLaunchKernelGGL((k_pw_nres<NB, true>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    else hipLaunchKernelGGL((k_pw_nres<NB, false>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32, const void* W,
+                          long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T,
+                          int P) {
+    if (K0 % 16 != 0 || K1 % 16 != 0 || N % 8 != 0 || NB * 32 < N) return hipErrorInvalidValue;
+    const f16* Wh = (const f16*)W;
+    switch (NB) {
+#define IRA_CASE(NB_) case NB_: return pw_nres_dispatch<NB_>(st, x0, K0, x1, K1, in_f32, Wh, w_tile_stride, bias, resid, y, N, T, P);
+        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(12)
+#undef IRA_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias, void* qk, void* v,
+                             int T, int H, int W, int C) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)T * H * ((W + 7) / 8) * (3 * C / 8);
+    hipLaunchKernelGGL(k_dwconv_qkv, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)qk,
+                       (f16*)v, T, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, const float* bias, void* out, int T,
+                              int H, int W, int Hp) {
+    if (Hp % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)T * H * ((W + 7) / 8) * (Hp / 8);
+    hipLaunchKernelGGL(k_dwconv_gate, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out,
+                       T, H, W, Hp);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int nblk, int C, int heads, int S) {
+    if (heads <= 0 || C % heads != 0 || (C / heads) % 16 != 0 || S <= 0) return hipErrorInvalidValue;
+    const long waves = (long)T * heads * S;
+    const dim3 grid(grid1d(waves, 4)), block(256);
+    const f16* q = (const f16*)qk;
+    switch (C / heads / 16) {
+        case 1: hipLaunchKernelGGL((k_gram<1>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
+        case 2: hipLaunchKernelGGL((k_gram<2>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
+        case 3: hipLaunchKernelGGL((k_gram<3>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
+        case 6: hipLaunchKernelGGL((k_gram<6>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, void* M, int T,
+                           int C, int heads, int S, int NB) {
+    const int c = C / heads;
+    const size_t smem = (size_t)(c * c + 2 * c) * sizeof(float);
+    hipLaunchKernelGGL(k_attn_mix, dim3(T * heads), dim3(256), smem, st, part, wo, temp, (f16*)M, T, C, heads, S, NB);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W, const float* bias,
+                                   const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB) {
+    const long waves = (long)T * (((long)H * Wd + 31) / 32);
+    const int NBW = NB >= 6 ? 6 : (NB >= 3 ? 3 : (NB == 2 ? 2 : 1));
+    const dim3 grid(grid1d(waves, 4), (NB + NBW - 1) / NBW), block(256);
+    switch (NBW) {
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+        default: hipLaunchKernelGGL((k_conv3x3<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias, const float* skip,
+                          float* out, int mode, int T, int H, int Wd, int K, int N, int NB) {
+    if (K % 16 != 0 || NB * 32 < N) return hipErrorInvalidValue;
+    if (mode == 1 && ((H | Wd) & 1)) return hipErrorInvalidValue;
+    if (mode == 2 && (N & 3)) return hipErrorInvalidValue;
+    if (mode == 3 && skip == nullptr) return hipErrorInvalidValue;
+    const f16* Wh = (const f16*)W;
+    switch (mode) {
+        case 0: return conv3x3_dispatch<0>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out, int T, int H,
+                        int W, int ic, int C) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const long total = (long)T * H * W * (C / 8);
+    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), 0, st, in, w, bias, out, T, H, W, ic, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx) {
+    if ((Ca | Cb) & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_concat2, dim3(grid1d(npx * ((Ca + Cb) / 4), 256, 65536)), dim3(256), 0, st, a, Ca, b, Cb, out, npx);
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int w, int c, int Hp, int Wp, int th,
+                                int tw, int stride_h, int stride_w, int n_rows, int n_cols, int first_tile,
+                                int n_tiles, float* tiles) {
+    const long total = (long)n_tiles * th * tw * c;
+    hipLaunchKernelGGL(k_extract_tiles, dim3(grid1d(total, 256, 65536)), dim3(256), 0, st, frame, h, w, c, Hp, Wp, th, tw,
+                       stride_h, stride_w, n_rows, n_cols, first_tile, n_tiles, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c, int Hp, int Wp, int th, int tw,
+                        int stride_h, int stride_w, int n_rows, int n_cols, uint8_t* out) {
+    const long total = (long)h * w * c;
+    hipLaunchKernelGGL(k_blend, dim3(grid1d(total, 256, 65536)), dim3(256), 0, st, tiles, h, w, c, Hp, Wp, th, tw, stride_h,
+                       stride_w, n_rows, n_cols, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* in, float* out, int B, int C, int H, int W) {
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid1d((long)B * C * H * W, 256, 65536)), dim3(256), 0, st, in, out, B, C, H, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int B, int C, int H, int W) {
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(grid1d((long)B * C * H * W, 256, 65536)), dim3(256), 0, st, in, out, B, C, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace ira

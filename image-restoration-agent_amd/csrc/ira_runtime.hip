@@ -1,0 +1,708 @@
+// libira_hip.so runtime: model handle, weight blob, workspace, Restormer forward schedule, tiler,
+// and the C ABI of include/ira.h.  No torch, no CPU compute fallback.
+//
+// Reference path this replaces: restormer_arch.py:245-284 (network), demo.py:109-168 /
+// model_serving.py:158-209 (harness).  See DESIGN.md for layouts.
+#include "../../include/ira.h"
+#include "ira_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;   // errors of calls that have no handle
+
+struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device pointers into the weight blob
+    const void* qkv_w = nullptr;  const float* qkv_b = nullptr;
+    const float* dw1_w = nullptr; const float* dw1_b = nullptr;
+    const float* temp = nullptr;  const float* wo = nullptr; const float* wo_b = nullptr;
+    const void* pin_w = nullptr;  const float* pin_b = nullptr;
+    const float* dw2_w = nullptr; const float* dw2_b = nullptr;
+    const void* pout_w = nullptr; const float* pout_b = nullptr;
+};
+
+struct Prof { long launches = 0; double ms = 0; };
+
+}  // namespace
+
+struct ira_model {
+    int device = -1;
+    ira_restormer_config cfg{};
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+    std::mutex mu;
+    std::string err, prof_json;
+    bool profile = false;
+    std::map<std::string, Prof> prof;
+
+    // weights
+    char* wblob = nullptr; size_t wbytes = 0;
+    std::map<std::string, std::pair<size_t, size_t>> toc;   // name -> (offset, nbytes)
+    std::vector<Blk> enc1, enc2, enc3, lat, dec3, dec2, dec1, refine;
+    const float* embed_w = nullptr; const float* embed_b = nullptr;
+    const void *down12 = nullptr, *down23 = nullptr, *down34 = nullptr, *up43 = nullptr, *up32 = nullptr, *up21 = nullptr;
+    const void *red3 = nullptr, *red2 = nullptr; const float *red3_b = nullptr, *red2_b = nullptr;
+    const void* out_w = nullptr; const float* out_b = nullptr;
+
+    // workspace
+    char* ws = nullptr; size_t ws_bytes = 0;
+    int ws_T = 0, ws_H = 0, ws_W = 0;
+    float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part;
+    void *qkvp, *qk, *v, *hp, *g, *M;
+    int max_batch = 0;
+    // harness scratch
+    char* hs = nullptr; size_t hs_bytes = 0;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace {
+
+int gfail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(m, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return (m)->fail(e_ == hipErrorOutOfMemory ? IRA_ERR_OOM : IRA_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                             hipGetErrorString(e_), __FILE__, __LINE__);                          \
+    } while (0)
+
+inline int up32(int n) { return (n + 31) / 32 * 32; }
+inline size_t al256(size_t n) { return (n + 255) / 256 * 256; }
+
+struct Geo {   // per-level geometry for a batch of T tiles of H x W
+    int H[4], W[4], C[4], heads[4], hid[4], Hp[4];
+    long P[4];
+};
+
+Geo make_geo(const ira_restormer_config& c, int H, int W) {
+    Geo g;
+    for (int l = 0; l < 4; ++l) {
+        g.H[l] = H >> l; g.W[l] = W >> l; g.P[l] = (long)g.H[l] * g.W[l];
+        g.C[l] = c.dim << l; g.heads[l] = c.heads[l]; g.hid[l] = c.hidden[l]; g.Hp[l] = up32(c.hidden[l]);
+    }
+    return g;
+}
+
+int gram_splits(int T, int heads, long nblk) {
+    // depends on the tile geometry only (never on T): a tile's result must not depend on what else is
+    // in its launch-batch, and the partials are reduced in fixed order (bitwise reproducible)
+    (void)T; (void)heads;
+    const long nsteps = (nblk + 3) / 4;
+    return (int)std::max(1L, std::min(nsteps / 64, 64L));
+}
+
+// ---- profiling wrapper: run one launch, optionally bracketed by events
+template <class F>
+int run(ira_model* m, const char* family, F&& f) {
+    if (m->profile) {
+        HIP_TRY(m, hipEventRecord(m->pev0, m->st));
+        HIP_TRY(m, f());
+        HIP_TRY(m, hipEventRecord(m->pev1, m->st));
+        HIP_TRY(m, hipEventSynchronize(m->pev1));
+        float ms = 0;
+        HIP_TRY(m, hipEventElapsedTime(&ms, m->pev0, m->pev1));
+        Prof& p = m->prof[family];
+        p.launches++; p.ms += ms;
+        return IRA_OK;
+    }
+    HIP_TRY(m, f());
+    return IRA_OK;
+}
+#define RUN(m, fam, call)                                        \
+    do {                                                         \
+        int rc_ = run((m), (fam), [&]() { return (call); });     \
+        if (rc_ != IRA_OK) return rc_;                           \
+    } while (0)
+
+// ---- weights
+struct TocEntry { char name[112]; uint64_t offset; uint64_t nbytes; };
+struct BlobHeader { char magic[8]; uint32_t n_entries; uint32_t reserved; };
+
+const void* wptr(ira_model* m, const std::string& name, bool required, size_t expect_bytes = 0) {
+    auto it = m->toc.find(name);
+    if (it == m->toc.end()) {
+        if (required) m->err = "weight blob: missing entry '" + name + "'";
+        return nullptr;
+    }
+    if (expect_bytes && it->second.second != expect_bytes) {
+        m->err = "weight blob: entry '" + name + "' has " + std::to_string(it->second.second) + " bytes, expected " +
+                 std::to_string(expect_bytes);
+        return nullptr;
+    }
+    return m->wblob + it->second.first;
+}
+
+bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, Blk& b) {
+    const size_t NBq = up32(3 * C), NBc = up32(C);
+    const bool cb = m->cfg.conv_bias != 0, lb = m->cfg.ln_with_bias != 0;
+    m->err.clear();
+    b.qkv_w = wptr(m, p + ".qkv_w", true, NBq * C * 2);
+    b.qkv_b = (const float*)wptr(m, p + ".qkv_b", cb || lb, NBq * 4);
+    b.dw1_w = (const float*)wptr(m, p + ".dw1_w", true, (size_t)9 * 3 * C * 4);
+    b.dw1_b = (const float*)wptr(m, p + ".dw1_b", cb, (size_t)3 * C * 4);
+    b.temp = (const float*)wptr(m, p + ".temp", true, (size_t)heads * 4);
+    b.wo = (const float*)wptr(m, p + ".wo", true, (size_t)C * C * 4);
+    b.wo_b = (const float*)wptr(m, p + ".wo_b", cb, NBc * 4);
+    b.pin_w = wptr(m, p + ".pin_w", true, (size_t)2 * Hp * C * 2);
+    b.pin_b = (const float*)wptr(m, p + ".pin_b", cb || lb, (size_t)2 * Hp * 4);
+    b.dw2_w = (const float*)wptr(m, p + ".dw2_w", true, (size_t)9 * 2 * Hp * 4);
+    b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
+    b.pout_w = wptr(m, p + ".pout_w", true, NBc * Hp * 2);
+    b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
+    return m->err.empty();
+}
+
+bool load_stage(ira_model* m, const char* name, int n, int C, int heads, int Hp, std::vector<Blk>& out) {
+    out.resize(n);
+    for (int i = 0; i < n; ++i)
+        if (!load_block(m, std::string(name) + "." + std::to_string(i), C, heads, Hp, out[i])) return false;
+    return true;
+}
+
+bool bind_weights(ira_model* m) {
+    const ira_restormer_config& c = m->cfg;
+    const Geo g = make_geo(c, 8, 8);
+    const bool cb = c.conv_bias != 0;
+    m->err.clear();
+    m->embed_w = (const float*)wptr(m, "embed_w", true, (size_t)c.dim * c.inp_channels * 9 * 4);
+    if (!m->embed_w) return false;
+    if (!load_stage(m, "encoder_level1", c.num_blocks[0], g.C[0], g.heads[0], g.Hp[0], m->enc1)) return false;
+    if (!load_stage(m, "encoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->enc2)) return false;
+    if (!load_stage(m, "encoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->enc3)) return false;
+    if (!load_stage(m, "latent", c.num_blocks[3], g.C[3], g.heads[3], g.Hp[3], m->lat)) return false;
+    if (!load_stage(m, "decoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->dec3)) return false;
+    if (!load_stage(m, "decoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->dec2)) return false;
+    // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
+    if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], m->dec1)) return false;
+    if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], m->refine)) return false;
+    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)9 * up32(N) * K * 2); };
+    m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
+    m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
+    m->down34 = c3("down3_4_w", g.C[2], g.C[2] / 2);
+    m->up43 = c3("up4_3_w", g.C[3], g.C[3] * 2);
+    m->up32 = c3("up3_2_w", g.C[2], g.C[2] * 2);
+    m->up21 = c3("up2_1_w", g.C[1], g.C[1] * 2);
+    m->red3 = wptr(m, "reduce3_w", true, (size_t)up32(g.C[2]) * g.C[3] * 2);
+    m->red2 = wptr(m, "reduce2_w", true, (size_t)up32(g.C[1]) * g.C[2] * 2);
+    m->red3_b = (const float*)wptr(m, "reduce3_b", cb, (size_t)up32(g.C[2]) * 4);
+    m->red2_b = (const float*)wptr(m, "reduce2_b", cb, (size_t)up32(g.C[1]) * 4);
+    m->out_w = c3("output_w", g.C[1], c.out_channels);
+    m->out_b = (const float*)wptr(m, "output_b", cb, (size_t)up32(c.out_channels) * 4);
+    m->embed_b = nullptr;   // OverlapPatchEmbed is always bias=False (restormer_arch.py:157)
+    return m->down12 && m->down23 && m->down34 && m->up43 && m->up32 && m->up21 && m->red3 && m->red2 && m->out_w &&
+           (!cb || (m->red3_b && m->red2_b && m->out_b));
+}
+
+// ---- workspace
+int ensure_workspace(ira_model* m, int T, int H, int W) {
+    if (m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W) return IRA_OK;
+    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
+    const Geo g = make_geo(m->cfg, H, W);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    const size_t t = (size_t)T;
+    size_t o_xe1 = take(t * g.P[0] * g.C[0] * 4), o_xe2 = take(t * g.P[1] * g.C[1] * 4), o_xe3 = take(t * g.P[2] * g.C[2] * 4),
+           o_x4 = take(t * g.P[3] * g.C[3] * 4), o_xd3 = take(t * g.P[2] * g.C[2] * 4), o_xd2 = take(t * g.P[1] * g.C[1] * 4),
+           o_xd1 = take(t * g.P[0] * g.C[1] * 4), o_u3 = take(t * g.P[2] * g.C[2] * 4), o_u2 = take(t * g.P[1] * g.C[1] * 4),
+           o_u1 = take(t * g.P[0] * g.C[0] * 4);
+    // branch scratch: max over the (level, channel) pairs actually run; level-1 decoder runs at 2*dim
+    size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int nvar = (l == 0) ? 2 : 1;
+        for (int var = 0; var < nvar; ++var) {
+            const int C = (var == 1) ? g.C[1] : g.C[l];
+            const int heads = g.heads[l];
+            const int Hp = (var == 1) ? g.Hp[1] : g.Hp[l];
+            const long nblk = (long)g.H[l] * ((g.W[l] + 7) / 8);
+            const int S = gram_splits(T, heads, nblk);
+            const int c = C / heads;
+            mq = std::max(mq, t * g.P[l] * 3 * C * 2);
+            mqk = std::max(mqk, t * nblk * 2 * C * 8 * 2);
+            mv = std::max(mv, t * g.P[l] * C * 2);
+            mh = std::max(mh, t * g.P[l] * 2 * Hp * 2);
+            mg = std::max(mg, t * g.P[l] * Hp * 2);
+            mM = std::max(mM, t * up32(C) * C * 2);
+            mpart = std::max(mpart, t * S * heads * ((size_t)c * c + 2 * c) * 4);
+        }
+    }
+    size_t o_q = take(mq), o_qk = take(mqk), o_v = take(mv), o_h = take(mh), o_g = take(mg), o_M = take(mM), o_p = take(mpart);
+    hipError_t e = hipMalloc((void**)&m->ws, off);
+    if (e != hipSuccess) {
+        m->ws = nullptr; m->ws_T = 0;
+        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, H, W, hipGetErrorString(e));
+    }
+    m->ws_bytes = off; m->ws_T = T; m->ws_H = H; m->ws_W = W;
+    char* b = m->ws;
+    m->xe1 = (float*)(b + o_xe1); m->xe2 = (float*)(b + o_xe2); m->xe3 = (float*)(b + o_xe3); m->x4 = (float*)(b + o_x4);
+    m->xd3 = (float*)(b + o_xd3); m->xd2 = (float*)(b + o_xd2); m->xd1 = (float*)(b + o_xd1);
+    m->u3 = (float*)(b + o_u3); m->u2 = (float*)(b + o_u2); m->u1 = (float*)(b + o_u1);
+    m->qkvp = b + o_q; m->qk = b + o_qk; m->v = b + o_v; m->hp = b + o_h; m->g = b + o_g; m->M = b + o_M;
+    m->part = (float*)(b + o_p);
+    // M rows >= C are MFMA padding and must read as zero
+    HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));
+    return IRA_OK;
+}
+
+int ensure_scratch(ira_model* m, size_t bytes) {
+    if (m->hs && bytes <= m->hs_bytes) return IRA_OK;
+    if (m->hs) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->hs)); m->hs = nullptr; m->hs_bytes = 0; }
+    hipError_t e = hipMalloc((void**)&m->hs, bytes);
+    if (e != hipSuccess) { m->hs = nullptr; return m->fail(IRA_ERR_OOM, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    m->hs_bytes = bytes;
+    return IRA_OK;
+}
+
+// ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
+int run_block(ira_model* m, const Blk& b, float* x, int T, int H, int W, int C, int heads, int Hp) {
+    const int P = H * W;
+    const int ln = m->cfg.ln_with_bias ? 2 : 1;
+    const int NBq = up32(3 * C) / 32, NBc = up32(C) / 32;
+    const long nblk = (long)H * ((W + 7) / 8);
+    const int S = gram_splits(T, heads, nblk);
+    hipStream_t st = m->st;
+    // MDTA (:111-132)
+    RUN(m, "ln_qkv_1x1", ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
+    RUN(m, "dwconv_qkv", ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
+    RUN(m, "gram", ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
+    RUN(m, "attn_mix", ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->M, T, C, heads, S, NBc));
+    RUN(m, "attn_apply_res", ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, (long)NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
+    // GDFN (:88-93)
+    RUN(m, "ln_pin_1x1", ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
+    RUN(m, "dwconv_gate", ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
+    RUN(m, "pout_res", ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
+    return IRA_OK;
+}
+
+int run_stage(ira_model* m, const std::vector<Blk>& blks, float* x, int T, int H, int W, int C, int heads, int Hp) {
+    for (const Blk& b : blks) {
+        int rc = run_block(m, b, x, T, H, W, C, heads, Hp);
+        if (rc != IRA_OK) return rc;
+    }
+    return IRA_OK;
+}
+
+// ---- Restormer.forward (restormer_arch.py:245-284) on device NHWC fp32, T tiles of H x W (enqueue only)
+int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    const ira_restormer_config& c = m->cfg;
+    if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
+        return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);
+    int rc = ensure_workspace(m, T, H, W);
+    if (rc != IRA_OK) return rc;
+    const Geo g = make_geo(c, H, W);
+    hipStream_t st = m->st;
+    auto nb = [](int N) { return up32(N) / 32; };
+
+    RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, m->xe1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
+    if ((rc = run_stage(m, m->enc1, m->xe1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                              // :248
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe1, m->down12, nullptr, nullptr, m->xe2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
+    if ((rc = run_stage(m, m->enc2, m->xe2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe2, m->down23, nullptr, nullptr, m->xe3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
+    if ((rc = run_stage(m, m->enc3, m->xe3, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe3, m->down34, nullptr, nullptr, m->x4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
+    if ((rc = run_stage(m, m->lat, m->x4, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                                // :257
+
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->x4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], m->xe3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, m->xd3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
+    if ((rc = run_stage(m, m->dec3, m->xd3, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->xd3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], m->xe2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, m->xd2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
+    if ((rc = run_stage(m, m->dec2, m->xd2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->xd2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
+    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], m->xe1, g.C[0], m->xd1, (long)T * g.P[0]));                                  // :270
+    if ((rc = run_stage(m, m->dec1, m->xd1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
+    if ((rc = run_stage(m, m->refine, m->xd1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
+    RUN(m, "conv3x3_out", ira::launch_conv3x3(st, m->xd1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
+    return IRA_OK;
+}
+
+struct Plan { int Hp, Wp, th, tw, sh, sw, n_rows, n_cols; };
+
+int make_plan(int h, int w, int tile, int overlap, Plan& p, std::string& err) {
+    if (h <= 0 || w <= 0) { err = "image size must be positive"; return IRA_ERR_ARG; }
+    // demo.py:123-126
+    const int H = ((h + 8) / 8) * 8, W = ((w + 8) / 8) * 8;
+    p.Hp = (h % 8 != 0) ? H : h;
+    p.Wp = (w % 8 != 0) ? W : w;
+    if (p.Hp - h >= h || p.Wp - w >= w) { err = "reflect padding needs pad < image size (F.pad 'reflect')"; return IRA_ERR_ARG; }
+    if (tile <= 0) {   // demo.py:129-131
+        p.th = p.Hp; p.tw = p.Wp; p.sh = p.Hp; p.sw = p.Wp; p.n_rows = 1; p.n_cols = 1;
+        return IRA_OK;
+    }
+    const int t = std::min(tile, std::min(p.Hp, p.Wp));                      // demo.py:135
+    if (t % 8 != 0) { err = "tile size should be multiple of 8"; return IRA_ERR_ARG; }   // demo.py:136
+    const int stride = t - overlap;                                           // demo.py:139
+    if (stride <= 0) { err = "tile_overlap must be smaller than the tile (range() step must be positive)"; return IRA_ERR_ARG; }
+    p.th = p.tw = t; p.sh = p.sw = stride;
+    // len(list(range(0, Hp - t, stride))) + 1   (demo.py:140-141)
+    p.n_rows = (p.Hp - t + stride - 1) / stride + 1;
+    p.n_cols = (p.Wp - t + stride - 1) / stride + 1;
+    return IRA_OK;
+}
+
+int default_batch(const ira_model* m, const Plan& p) {
+    if (m->max_batch > 0) return m->max_batch;
+    // keep a launch-batch around <= 8 tiles of 512x512 (about 8 GB of workspace); more for small tiles
+    const long px = (long)p.th * p.tw;
+    long b = (8L * 512 * 512) / std::max(px, 1L);
+    return (int)std::max(1L, std::min(b, 64L));
+}
+
+int restore_tiles_enqueue(ira_model* m, const uint8_t* frame_dev, int h, int w, int c, const Plan& p, int first,
+                          int n, float* tiles_out) {
+    const int batch = default_batch(m, p);
+    const size_t tile_elems = (size_t)p.th * p.tw * c;
+    int rc = ensure_scratch(m, al256((size_t)batch * tile_elems * 4));
+    if (rc != IRA_OK) return rc;
+    float* tin = (float*)m->hs;
+    for (int t0 = 0; t0 < n; t0 += batch) {
+        const int nb = std::min(batch, n - t0);
+        RUN(m, "tile_extract", ira::launch_extract_tiles(m->st, frame_dev, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw,
+                                                         p.n_rows, p.n_cols, first + t0, nb, tin));
+        rc = forward_enqueue(m, tin, nb, p.th, p.tw, tiles_out + (size_t)t0 * tile_elems);
+        if (rc != IRA_OK) return rc;
+    }
+    return IRA_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int ira_device_count(int* count) {
+    if (!count) return gfail(IRA_ERR_ARG, "ira_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return gfail(IRA_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, i) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    *count = ok;
+    return IRA_OK;
+}
+
+int ira_model_create(int device, const ira_restormer_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_model_create: NULL argument");
+    *out = nullptr;
+    if (cfg->dual_pixel_task) return gfail(IRA_ERR_ARG, "dual_pixel_task is not supported (not dispatched by the agent)");
+    if (cfg->dim <= 0 || cfg->dim % 16 != 0) return gfail(IRA_ERR_ARG, "dim must be a positive multiple of 16, got %d", cfg->dim);
+    if (cfg->inp_channels != cfg->out_channels || (cfg->inp_channels != 1 && cfg->inp_channels != 3))
+        return gfail(IRA_ERR_ARG, "inp_channels == out_channels in {1,3} required, got %d/%d", cfg->inp_channels, cfg->out_channels);
+    for (int l = 0; l < 4; ++l) {
+        const int C = cfg->dim << l;
+        if (cfg->heads[l] <= 0 || C % cfg->heads[l] != 0 || (C / cfg->heads[l]) % 16 != 0)
+            return gfail(IRA_ERR_ARG, "level %d: C=%d heads=%d needs C/heads to be a multiple of 16", l, C, cfg->heads[l]);
+        const int c = C / cfg->heads[l];
+        if (c != 16 && c != 32 && c != 48 && c != 96) return gfail(IRA_ERR_ARG, "level %d: per-head channels %d not in {16,32,48,96}", l, c);
+        if (cfg->hidden[l] <= 0) return gfail(IRA_ERR_ARG, "hidden[%d] must be positive", l);
+    }
+    {   // decoder level 1 / refinement: 2*dim channels on heads[0]
+        const int c = 2 * cfg->dim / cfg->heads[0];
+        if ((2 * cfg->dim) % cfg->heads[0] != 0 || (c != 16 && c != 32 && c != 48 && c != 96))
+            return gfail(IRA_ERR_ARG, "decoder level 1: per-head channels %d not in {16,32,48,96}", c);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return gfail(IRA_ERR_NO_DEVICE, "no HIP device visible: libira_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return gfail(IRA_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess || strncmp(pr.gcnArchName, "gfx950", 6) != 0)
+        return gfail(IRA_ERR_NO_DEVICE, "device %d is '%s', this library carries gfx950 code only", device, pr.gcnArchName);
+
+    // parse blob table of contents
+    if (bytes < sizeof(BlobHeader)) return gfail(IRA_ERR_WEIGHTS, "weight blob too small");
+    const BlobHeader* hd = (const BlobHeader*)blob;
+    if (memcmp(hd->magic, "IRAWGT1", 8) != 0) return gfail(IRA_ERR_WEIGHTS, "weight blob: bad magic");
+    const size_t toc_end = sizeof(BlobHeader) + (size_t)hd->n_entries * sizeof(TocEntry);
+    if (toc_end > bytes) return gfail(IRA_ERR_WEIGHTS, "weight blob: truncated table of contents");
+
+    ira_model* m = new ira_model();
+    m->device = device; m->cfg = *cfg;
+    const TocEntry* te = (const TocEntry*)((const char*)blob + sizeof(BlobHeader));
+    for (uint32_t i = 0; i < hd->n_entries; ++i) {
+        if (te[i].offset + te[i].nbytes > bytes || te[i].offset % 256 != 0) {
+            delete m; return gfail(IRA_ERR_WEIGHTS, "weight blob: entry %u out of bounds / misaligned", i);
+        }
+        char nm[113]; memcpy(nm, te[i].name, 112); nm[112] = 0;
+        m->toc[nm] = {(size_t)te[i].offset, (size_t)te[i].nbytes};
+    }
+    auto bail = [&](int code, const std::string& why) {
+        g_err = why;
+        if (m->wblob) hipFree(m->wblob);
+        if (m->st) hipStreamDestroy(m->st);
+        if (m->ev0) hipEventDestroy(m->ev0);
+        if (m->ev1) hipEventDestroy(m->ev1);
+        if (m->pev0) hipEventDestroy(m->pev0);
+        if (m->pev1) hipEventDestroy(m->pev1);
+        delete m;
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->pev0) != hipSuccess ||
+        hipEventCreate(&m->pev1) != hipSuccess)
+        return bail(IRA_ERR_HIP, "hipEventCreate failed");
+    if ((e = hipMalloc((void**)&m->wblob, bytes)) != hipSuccess) { m->wblob = nullptr; return bail(IRA_ERR_OOM, std::string("weights hipMalloc: ") + hipGetErrorString(e)); }
+    m->wbytes = bytes;
+    if ((e = hipMemcpy(m->wblob, blob, bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("weights upload: ") + hipGetErrorString(e));
+    if (!bind_weights(m)) return bail(IRA_ERR_WEIGHTS, m->err.empty() ? "weight blob: missing entries" : m->err);
+    *out = m;
+    return IRA_OK;
+}
+
+int ira_model_destroy(ira_model_t* m) {
+    if (!m) return IRA_OK;
+    hipSetDevice(m->device);
+    if (m->st) hipStreamSynchronize(m->st);
+    if (m->ws) hipFree(m->ws);
+    if (m->hs) hipFree(m->hs);
+    if (m->wblob) hipFree(m->wblob);
+    if (m->ev0) hipEventDestroy(m->ev0);
+    if (m->ev1) hipEventDestroy(m->ev1);
+    if (m->pev0) hipEventDestroy(m->pev0);
+    if (m->pev1) hipEventDestroy(m->pev1);
+    if (m->st) hipStreamDestroy(m->st);
+    delete m;
+    return IRA_OK;
+}
+
+const char* ira_last_error(const ira_model_t* m) { return m ? m->err.c_str() : g_err.c_str(); }
+
+#define ENTER(m)                                                     \
+    if (!(m)) return gfail(IRA_ERR_ARG, "%s: model is NULL", __func__); \
+    std::lock_guard<std::mutex> lock_((m)->mu);                      \
+    HIP_TRY((m), hipSetDevice((m)->device))
+
+int ira_sync(ira_model_t* m) {
+    ENTER(m);
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_forward_device(ira_model_t* m, const float* in, int B, int H, int W, float* out) {
+    ENTER(m);
+    if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_forward_device: NULL buffer");
+    int rc = forward_enqueue(m, in, B, H, W, out);
+    if (rc != IRA_OK) return rc;
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, float* out) {
+    ENTER(m);
+    if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_forward: NULL buffer");
+    if (C != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "ira_forward: C=%d but the model has inp_channels=%d", C, m->cfg.inp_channels);
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7)) return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
+    const size_t n = (size_t)B * C * H * W;
+    int rc = ensure_scratch(m, 3 * al256(n * 4));
+    if (rc != IRA_OK) return rc;
+    float* a = (float*)m->hs;                       // NCHW staging (in, then out)
+    float* nhwc_in = (float*)(m->hs + al256(n * 4));
+    float* nhwc_out = (float*)(m->hs + 2 * al256(n * 4));
+    HIP_TRY(m, hipMemcpyAsync(a, in, n * 4, hipMemcpyHostToDevice, m->st));
+    RUN(m, "layout", ira::launch_nchw_to_nhwc(m->st, a, nhwc_in, B, C, H, W));
+    rc = forward_enqueue(m, nhwc_in, B, H, W, nhwc_out);
+    if (rc != IRA_OK) return rc;
+    RUN(m, "layout", ira::launch_nhwc_to_nchw(m->st, nhwc_out, a, B, C, H, W));
+    HIP_TRY(m, hipMemcpyAsync(out, a, n * 4, hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_tile_plan(int h, int w, int tile, int overlap, int* Hp, int* Wp, int* th, int* tw, int* n_rows, int* n_cols) {
+    Plan p; std::string err;
+    int rc = make_plan(h, w, tile, overlap, p, err);
+    if (rc != IRA_OK) return gfail(rc, "%s", err.c_str());
+    if (Hp) *Hp = p.Hp; if (Wp) *Wp = p.Wp; if (th) *th = p.th; if (tw) *tw = p.tw;
+    if (n_rows) *n_rows = p.n_rows; if (n_cols) *n_cols = p.n_cols;
+    return IRA_OK;
+}
+
+int ira_restore_tiles_device(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap,
+                             int first_tile, int n_tiles, float* tiles_out) {
+    ENTER(m);
+    if (!frame || !tiles_out) return m->fail(IRA_ERR_ARG, "ira_restore_tiles_device: NULL buffer");
+    if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
+    Plan p; std::string err;
+    int rc = make_plan(h, w, tile, overlap, p, err);
+    if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
+    if (first_tile < 0 || n_tiles < 0 || first_tile + n_tiles > p.n_rows * p.n_cols)
+        return m->fail(IRA_ERR_ARG, "tile range [%d,%d) outside the %dx%d plan", first_tile, first_tile + n_tiles, p.n_rows, p.n_cols);
+    if (n_tiles == 0) return IRA_OK;
+    rc = restore_tiles_enqueue(m, frame, h, w, c, p, first_tile, n_tiles, tiles_out);
+    if (rc != IRA_OK) return rc;
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_blend_tiles_device(ira_model_t* m, const float* tiles, int h, int w, int c, int tile, int overlap, uint8_t* out) {
+    ENTER(m);
+    if (!tiles || !out) return m->fail(IRA_ERR_ARG, "ira_blend_tiles_device: NULL buffer");
+    Plan p; std::string err;
+    int rc = make_plan(h, w, tile, overlap, p, err);
+    if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
+    RUN(m, "tile_blend", ira::launch_blend(m->st, tiles, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw, p.n_rows, p.n_cols, out));
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_restore_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int tile, int overlap, uint8_t* out) {
+    if (!m) return gfail(IRA_ERR_ARG, "ira_restore_u8: model is NULL");
+    Plan p; std::string err;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_restore_u8: NULL buffer");
+        if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
+        int rc = make_plan(h, w, tile, overlap, p, err);
+        if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
+    }
+    ENTER(m);
+    const int nt = p.n_rows * p.n_cols;
+    const size_t fbytes = (size_t)h * w * c;
+    const size_t tbytes = (size_t)nt * p.th * p.tw * c * 4;
+    uint8_t *fin = nullptr, *fout = nullptr; float* tiles = nullptr;
+    auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tiles) hipFree(tiles); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, fbytes)) != hipSuccess ||
+        (e = hipMalloc((void**)&tiles, tbytes)) != hipSuccess) {
+        cleanup();
+        return m->fail(IRA_ERR_OOM, "ira_restore_u8: hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = IRA_OK;
+    do {
+        if ((e = hipMemcpyAsync(fin, in, fbytes, hipMemcpyHostToDevice, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
+        if ((rc = restore_tiles_enqueue(m, fin, h, w, c, p, 0, nt, tiles)) != IRA_OK) break;
+        rc = run(m, "tile_blend", [&]() { return ira::launch_blend(m->st, tiles, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw, p.n_rows, p.n_cols, fout); });
+        if (rc != IRA_OK) break;
+        if ((e = hipMemcpyAsync(out, fout, fbytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
+        if ((e = hipStreamSynchronize(m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc != IRA_OK) hipStreamSynchronize(m->st);
+    cleanup();
+    return rc;
+}
+
+int ira_set_max_batch(ira_model_t* m, int max_tiles) {
+    ENTER(m);
+    if (max_tiles < 0) return m->fail(IRA_ERR_ARG, "max_tiles must be >= 0");
+    m->max_batch = max_tiles;
+    return IRA_OK;
+}
+
+int ira_timer_start(ira_model_t* m) {
+    ENTER(m);
+    HIP_TRY(m, hipEventRecord(m->ev0, m->st));
+    return IRA_OK;
+}
+
+int ira_timer_stop(ira_model_t* m, float* ms) {
+    ENTER(m);
+    if (!ms) return m->fail(IRA_ERR_ARG, "ira_timer_stop: NULL");
+    HIP_TRY(m, hipEventRecord(m->ev1, m->st));
+    HIP_TRY(m, hipEventSynchronize(m->ev1));
+    HIP_TRY(m, hipEventElapsedTime(ms, m->ev0, m->ev1));
+    return IRA_OK;
+}
+
+int ira_profile_enable(ira_model_t* m, int on) {
+    ENTER(m);
+    m->profile = on != 0;
+    if (on) m->prof.clear();
+    return IRA_OK;
+}
+
+const char* ira_profile_json(ira_model_t* m) {
+    if (!m) return "{}";
+    std::lock_guard<std::mutex> lk(m->mu);
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : m->prof) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f}", first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms);
+        s += buf; first = false;
+    }
+    s += "}";
+    m->prof_json = s;
+    return m->prof_json.c_str();
+}
+
+int ira_memory_bytes(ira_model_t* m, size_t* bytes) {
+    ENTER(m);
+    if (!bytes) return m->fail(IRA_ERR_ARG, "NULL");
+    *bytes = m->wbytes + m->ws_bytes + m->hs_bytes;
+    return IRA_OK;
+}
+
+// ------------------------------------------------------------------ single-kernel entry points
+#define OP_BODY(m, fam, call)             \
+    ENTER(m);                             \
+    RUN(m, fam, call);                    \
+    HIP_TRY(m, hipStreamSynchronize(m->st)); \
+    return IRA_OK
+
+int ira_op_pw_kres(ira_model_t* m, const void* x, int in_f32, int ln_mode, int K, const void* W, const float* bias,
+                   void* y, int y_stride, int n_store, int NB, int T, int P) {
+    OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P));
+}
+
+int ira_op_pw_nres(ira_model_t* m, const void* x0, int K0, const void* x1, int K1, int in_f32, const void* W,
+                   long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T, int P) {
+    OP_BODY(m, "op", ira::launch_pw_nres(m->st, x0, K0, x1, K1, in_f32 != 0, W, w_tile_stride, bias, resid, y, N, NB, T, P));
+}
+
+int ira_op_dwconv_qkv(ira_model_t* m, const void* in, const float* w, const float* bias, void* qk, void* v, int T,
+                      int H, int W, int C) {
+    OP_BODY(m, "op", ira::launch_dwconv_qkv(m->st, in, w, bias, qk, v, T, H, W, C));
+}
+
+int ira_op_dwconv_gate(ira_model_t* m, const void* in, const float* w, const float* bias, void* out, int T, int H,
+                       int W, int Hp) {
+    OP_BODY(m, "op", ira::launch_dwconv_gate(m->st, in, w, bias, out, T, H, W, Hp));
+}
+
+int ira_op_gram(ira_model_t* m, const void* qk, float* part, int T, int nblk, int C, int heads, int S) {
+    OP_BODY(m, "op", ira::launch_gram(m->st, qk, part, T, nblk, C, heads, S));
+}
+
+int ira_op_attn_mix(ira_model_t* m, const float* part, const float* wo, const float* temp, void* M, int T, int C,
+                    int heads, int S, int NB) {
+    OP_BODY(m, "op", ira::launch_attn_mix(m->st, part, wo, temp, M, T, C, heads, S, NB));
+}
+
+int ira_op_conv3x3(ira_model_t* m, const float* in, const void* W, const float* bias, const float* skip, float* out,
+                   int mode, int T, int H, int Wd, int K, int N, int NB) {
+    OP_BODY(m, "op", ira::launch_conv3x3(m->st, in, W, bias, skip, out, mode, T, H, Wd, K, N, NB));
+}
+
+int ira_op_embed(ira_model_t* m, const float* in, const float* w, const float* bias, float* out, int T, int H, int W,
+                 int ic, int C) {
+    OP_BODY(m, "op", ira::launch_embed(m->st, in, w, bias, out, T, H, W, ic, C));
+}
+
+int ira_op_concat2(ira_model_t* m, const float* a, int Ca, const float* b, int Cb, float* out, long npx) {
+    OP_BODY(m, "op", ira::launch_concat2(m->st, a, Ca, b, Cb, out, npx));
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""ctypes binding of libira_hip.so (include/ira.h).  Thin: argument marshalling and error raising only.
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is visible, the
+product path raises (``IraError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libira_hip.so')
+
+
+class IraError(RuntimeError):
+    pass
+
+
+class IraConfig(C.Structure):
+    _fields_ = [
+        ('inp_channels', C.c_int32), ('out_channels', C.c_int32), ('dim', C.c_int32),
+        ('num_blocks', C.c_int32 * 4), ('num_refinement_blocks', C.c_int32),
+        ('heads', C.c_int32 * 4), ('hidden', C.c_int32 * 4),
+        ('ln_with_bias', C.c_int32), ('conv_bias', C.c_int32), ('dual_pixel_task', C.c_int32),
+    ]
+
+
+_vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+_pi = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes): every symbol include/ira.h declares
+SIGNATURES = {
+    'ira_device_count': (_i, [_pi]),
+    'ira_model_create': (_i, [_i, C.POINTER(IraConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_model_destroy': (_i, [_vp]),
+    'ira_last_error': (C.c_char_p, [_vp]),
+    'ira_sync': (_i, [_vp]),
+    'ira_forward': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'ira_forward_device': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'ira_tile_plan': (_i, [_i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi]),
+    'ira_restore_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ira_restore_tiles_device': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ira_blend_tiles_device': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ira_set_max_batch': (_i, [_vp, _i]),
+    'ira_timer_start': (_i, [_vp]),
+    'ira_timer_stop': (_i, [_vp, C.POINTER(C.c_float)]),
+    'ira_profile_enable': (_i, [_vp, _i]),
+    'ira_profile_json': (C.c_char_p, [_vp]),
+    'ira_memory_bytes': (_i, [_vp, C.POINTER(_sz)]),
+    'ira_op_pw_kres': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_pw_nres': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_op_dwconv_qkv': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_op_dwconv_gate': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_op_gram': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_attn_mix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_conv3x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_concat2': (_i, [_vp, _vp, _i, _vp, _i, _vp, _l]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libira_hip.so and attach prototypes. Raises IraError when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get('IRA_HIP_LIB', LIB_PATH)
+    if not os.path.exists(p):
+        raise IraError(f"{p} not found: build it with `make -C image-restoration-agent_amd/csrc` "
+                       "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:   # missing libamdhip64 etc.
+        raise IraError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def last_error(handle=None) -> str:
+    lib = load_library()
+    s = lib.ira_last_error(handle)
+    return s.decode(errors='replace') if s else ''
+
+
+def check(rc: int, handle=None, what: str = ''):
+    if rc != 0:
+        raise IraError(f"{what or 'libira_hip'} failed (code {rc}): {last_error(handle)}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.ira_device_count(C.byref(n))
+    if rc != 0:
+        return 0
+    return n.value
+
+
+def tile_plan(h: int, w: int, tile, overlap: int):
+    """(Hp, Wp, tile_h, tile_w, n_rows, n_cols) of the reference tiler (demo.py:122-141)."""
+    lib = load_library()
+    v = [C.c_int(0) for _ in range(6)]
+    rc = lib.ira_tile_plan(h, w, int(tile) if tile else 0, int(overlap), *[C.byref(x) for x in v])
+    check(rc, None, 'ira_tile_plan')
+    return tuple(x.value for x in v)

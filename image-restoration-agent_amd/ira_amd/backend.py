@@ -1,0 +1,142 @@
+"""Python handle on one libira_hip model (one GPU, one stream).
+
+Replaces, for the Restormer tool, what the reference builds per process in demo.py:92-103 /
+model_serving.py:101-124 (instantiate arch, load ``checkpoint['params']``, ``.to(device)``, ``.eval()``)
+and what it calls per image (``model(input_)`` / the tiler loop, demo.py:129-153).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _capi
+from ._capi import IraConfig, IraError, check
+from .config import RestormerConfig
+from .pack import pack_blob
+
+
+def _cfg_struct(cfg: RestormerConfig) -> IraConfig:
+    s = IraConfig()
+    s.inp_channels, s.out_channels, s.dim = cfg.inp_channels, cfg.out_channels, cfg.dim
+    for i in range(4):
+        s.num_blocks[i] = cfg.num_blocks[i]
+        s.heads[i] = cfg.heads[i]
+        s.hidden[i] = cfg.hidden(cfg.dim * 2 ** i)     # int(dim*ffn_expansion_factor), restormer_arch.py:80
+    s.num_refinement_blocks = cfg.num_refinement_blocks
+    s.ln_with_bias = 0 if cfg.LayerNorm_type == 'BiasFree' else 1
+    s.conv_bias = 1 if cfg.bias else 0
+    s.dual_pixel_task = 1 if cfg.dual_pixel_task else 0
+    return s
+
+
+class RestormerBackend:
+    """One Restormer on one MI355X.  ``state_dict``: the reference's name -> tensor mapping
+    (torch tensors or numpy arrays), e.g. ``torch.load(path)['params']``."""
+
+    def __init__(self, cfg: RestormerConfig, state_dict, device: int = 0):
+        self._lib = _capi.load_library()
+        self.cfg = cfg
+        self.device = int(device)
+        self._h = C.c_void_p(None)
+        if _capi.device_count() <= 0:
+            raise IraError("no gfx950 (MI355X) device visible; this backend has no CPU fallback")
+        blob = pack_blob(state_dict, cfg)
+        cs = _cfg_struct(cfg)
+        h = C.c_void_p(None)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        rc = self._lib.ira_model_create(self.device, C.byref(cs), buf, len(blob), C.byref(h))
+        check(rc, None, 'ira_model_create')
+        self._h = h
+
+    # -- life cycle
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.ira_model_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _ck(self, rc, what):
+        check(rc, self._h, what)
+
+    # -- network
+    def forward(self, x_nchw: np.ndarray) -> np.ndarray:
+        """``model(input_)`` (demo.py:131): float32 (B,C,H,W) in, float32 (B,C,H,W) out."""
+        x = np.ascontiguousarray(x_nchw, dtype=np.float32)
+        if x.ndim != 4:
+            raise ValueError("expected (B,C,H,W)")
+        B, Cc, H, W = x.shape
+        out = np.empty_like(x)
+        self._ck(self._lib.ira_forward(self._h, x.ctypes.data, B, Cc, H, W, out.ctypes.data), 'ira_forward')
+        return out
+
+    def forward_device(self, in_ptr: int, B: int, H: int, W: int, out_ptr: int):
+        """float32 NHWC device tensors (raw pointers, e.g. torch.Tensor.data_ptr())."""
+        self._ck(self._lib.ira_forward_device(self._h, in_ptr, B, H, W, out_ptr), 'ira_forward_device')
+
+    # -- harness
+    def restore(self, img_u8: np.ndarray, tile=None, tile_overlap: int = 32) -> np.ndarray:
+        """uint8 (h,w,c) -> uint8 (h,w,c): pad -> whole/tiled forward -> average -> clamp -> crop -> uint8
+        (demo.py:120-161).  ``tile=None`` is the whole-image mode (demo.py:129-131)."""
+        img = np.ascontiguousarray(img_u8)
+        if img.dtype != np.uint8 or img.ndim != 3:
+            raise ValueError("expected a uint8 (h,w,c) array")
+        h, w, c = img.shape
+        out = np.empty_like(img)
+        rc = self._lib.ira_restore_u8(self._h, img.ctypes.data, h, w, c, int(tile) if tile else 0,
+                                      int(tile_overlap), out.ctypes.data)
+        self._ck(rc, 'ira_restore_u8')
+        return out
+
+    def restore_tiles_device(self, frame_ptr: int, h: int, w: int, c: int, tile, overlap: int,
+                             first_tile: int, n_tiles: int, out_ptr: int):
+        rc = self._lib.ira_restore_tiles_device(self._h, frame_ptr, h, w, c, int(tile) if tile else 0, int(overlap),
+                                                first_tile, n_tiles, out_ptr)
+        self._ck(rc, 'ira_restore_tiles_device')
+
+    def blend_tiles_device(self, tiles_ptr: int, h: int, w: int, c: int, tile, overlap: int, out_ptr: int):
+        rc = self._lib.ira_blend_tiles_device(self._h, tiles_ptr, h, w, c, int(tile) if tile else 0, int(overlap), out_ptr)
+        self._ck(rc, 'ira_blend_tiles_device')
+
+    # -- measurement
+    def set_max_batch(self, n: int):
+        self._ck(self._lib.ira_set_max_batch(self._h, int(n)), 'ira_set_max_batch')
+
+    def sync(self):
+        self._ck(self._lib.ira_sync(self._h), 'ira_sync')
+
+    def timer_start(self):
+        self._ck(self._lib.ira_timer_start(self._h), 'ira_timer_start')
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        self._ck(self._lib.ira_timer_stop(self._h, C.byref(ms)), 'ira_timer_stop')
+        return float(ms.value)
+
+    def profile_enable(self, on: bool):
+        self._ck(self._lib.ira_profile_enable(self._h, 1 if on else 0), 'ira_profile_enable')
+
+    def profile(self) -> dict:
+        s = self._lib.ira_profile_json(self._h)
+        return json.loads(s.decode()) if s else {}
+
+    def memory_bytes(self) -> int:
+        n = C.c_size_t(0)
+        self._ck(self._lib.ira_memory_bytes(self._h, C.byref(n)), 'ira_memory_bytes')
+        return int(n.value)

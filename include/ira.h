@@ -1,0 +1,191 @@
+/* ira.h -- C ABI of libira_hip.so, the MI355X (gfx950) restoration-inference backend.
+ *
+ * This is the drop-in boundary for the hot path of blackbean001/Image-Restoration-Agent: the
+ * Restormer restoration forward + sliding-window tiler that the agent reaches through
+ *   AgenticIR/executor/tool.py:33-78            Tool.__call__ -> _invoke (subprocess "python demo.py ...")
+ *   AgentApp/model_service/denoising/Restormer/model_serving.py:158-209   RestormerService.restore_image
+ * Plain pointers and sizes only; no torch / C++ types.  Python binds it with ctypes
+ * (image-restoration-agent_amd/ira_amd/_capi.py); INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; ira_last_error() gives the text.
+ *     Nothing throws or aborts.  There is NO CPU fallback: without a gfx950 device every compute
+ *     entry point fails with IRA_ERR_NO_DEVICE.
+ *   - "host" pointers are ordinary memory owned by the caller; "dev" pointers are HIP device
+ *     allocations on the model's device, also owned by the caller (e.g. a torch.cuda tensor's
+ *     data_ptr()).  The library owns weights, workspaces and one HIP stream per model.
+ *   - one model handle = one device + one stream, calls on it are serialised by an internal mutex;
+ *     handles on different devices are independent (one process per GPU is the intended use).
+ *   - all compute entry points are synchronous with respect to the host (they return after the
+ *     model stream has drained) unless named *_async.
+ *   - image layout: uint8 HWC (interleaved), as cv2/PIL hand it over in the reference
+ *     (demo.py:40-41,118).  Network tensors at the ABI: float32 NCHW on the host (what
+ *     ``model(input_)`` takes, demo.py:120,131) or float32 NHWC on the device.
+ */
+#ifndef IRA_H
+#define IRA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRA_OK             0
+#define IRA_ERR_ARG        1
+#define IRA_ERR_NO_DEVICE  2
+#define IRA_ERR_HIP        3
+#define IRA_ERR_WEIGHTS    4
+#define IRA_ERR_OOM        5
+
+typedef struct ira_model ira_model_t;
+
+/* Constructor arguments of the reference Restormer (restormer_arch.py:193-205). hidden[l] is
+ * int(dim_l * ffn_expansion_factor) (restormer_arch.py:80), computed by the caller so that the
+ * float -> int truncation is done once, in Python, exactly as the reference does it. */
+typedef struct ira_restormer_config {
+    int32_t inp_channels;            /* 3, or 1 for Gaussian_Gray_Denoising (demo.py:66-67) */
+    int32_t out_channels;
+    int32_t dim;                     /* 48 */
+    int32_t num_blocks[4];           /* {4,6,6,8} */
+    int32_t num_refinement_blocks;   /* 4 */
+    int32_t heads[4];                /* {1,2,4,8} */
+    int32_t hidden[4];               /* int(2.66*dim*2^l): {127,255,510,1021} */
+    int32_t ln_with_bias;            /* 0 = BiasFree (denoising tasks, demo.py:61,64,69), 1 = WithBias */
+    int32_t conv_bias;               /* 'bias' argument; False in every reference task (demo.py:92) */
+    int32_t dual_pixel_task;         /* must be 0 (not dispatched by the agent) */
+} ira_restormer_config;
+
+/* ------------------------------------------------------------------ life cycle */
+
+/* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
+int ira_device_count(int* count);
+
+/* Build a model on `device` from a packed weight blob (ira_amd/pack.py writes it from the
+ * reference state_dict: checkpoint['params'], demo.py:101-102). The blob is copied; the caller
+ * may free it after the call.  replaces: load_arch['Restormer'](**parameters); model.to(device);
+ * model.load_state_dict(...); model.eval()  (demo.py:95-103, model_serving.py:101-124). */
+int ira_model_create(int device, const ira_restormer_config* cfg,
+                     const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+int ira_model_destroy(ira_model_t* model);
+
+/* Text of the last error on this handle (or, with model == NULL, of the last failed call that had
+ * no handle, e.g. ira_model_create). Valid until the next call on the same handle/thread. */
+const char* ira_last_error(const ira_model_t* model);
+
+/* Block until the model stream has drained. */
+int ira_sync(ira_model_t* model);
+
+/* ------------------------------------------------------------------ network forward */
+
+/* restored = model(input_)  (demo.py:131,148; restormer_arch.py:245-284).
+ * in/out: float32 NCHW host buffers of B*C*H*W elements, C == cfg.inp_channels (== out_channels).
+ * H, W must be multiples of 8 (the harness pads, demo.py:122-127). */
+int ira_forward(ira_model_t* model, const float* in_nchw_host, int B, int C, int H, int W,
+                float* out_nchw_host);
+
+/* Same on device-resident float32 NHWC tensors (B,H,W,C). */
+int ira_forward_device(ira_model_t* model, const float* in_nhwc_dev, int B, int H, int W,
+                       float* out_nhwc_dev);
+
+/* ------------------------------------------------------------------ harness (demo.py:109-168) */
+
+/* Tiling plan of the overlap-average tiler (demo.py:122-141): padded size (Hp, Wp), effective tile
+ * = min(tile, Hp, Wp) (must be a multiple of 8), index lists list(range(0, Hp-tile, stride)) +
+ * [Hp-tile].  tile <= 0 means "whole image" (demo.py:129-131): one tile of Hp x Wp.
+ * Host-only; any output pointer may be NULL. */
+int ira_tile_plan(int h, int w, int tile, int overlap,
+                  int* Hp, int* Wp, int* tile_h, int* tile_w, int* n_rows, int* n_cols);
+
+/* Whole harness on host buffers: uint8 HWC in -> uint8 HWC out, h*w*c bytes each.
+ * /255 -> reflect-pad-if-needed -> whole / tiled forward -> E/W average -> clamp -> crop ->
+ * round-half-even*255.  replaces RestormerService.restore_image minus PNG (de)coding
+ * (model_serving.py:158-209) and the per-file body of demo.py:113-161. */
+int ira_restore_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h, int w, int c,
+                   int tile, int overlap, uint8_t* out_hwc_host);
+
+/* Sharded form for one-process-per-GPU tile parallelism.  All pointers are device
+ * memory.  frame: uint8 (h,w,c), unpadded.  Runs tiles [first_tile, first_tile+n_tiles) of the
+ * row-major tile list through the network and writes them, float32 NHWC (n_tiles,tile_h,tile_w,c),
+ * to tiles_out.  The caller all-gathers tiles_out across ranks (RCCL) and calls ira_blend_tiles_device. */
+int ira_restore_tiles_device(ira_model_t* model, const uint8_t* frame_u8_dev, int h, int w, int c,
+                             int tile, int overlap, int first_tile, int n_tiles, float* tiles_out_dev);
+
+/* E/W overlap average in row-major tile order (demo.py:145-153), clamp(0,1), crop to (h,w),
+ * rint(x*255) -> uint8 (demo.py:155-161).  tiles_dev holds ALL n_rows*n_cols tiles. */
+int ira_blend_tiles_device(ira_model_t* model, const float* tiles_dev, int h, int w, int c,
+                           int tile, int overlap, uint8_t* out_u8_dev);
+
+/* ------------------------------------------------------------------ measurement */
+
+/* Upper bound on tiles per network launch (workspace is sized for it lazily). 0 = default. */
+int ira_set_max_batch(ira_model_t* model, int max_tiles);
+
+/* HIP-event timer on the model stream (the stream the kernels are launched on). */
+int ira_timer_start(ira_model_t* model);
+int ira_timer_stop(ira_model_t* model, float* elapsed_ms);
+
+/* Per-kernel-family HIP-event timing.  enable(1) makes every launch bracketed by events (slow);
+ * ira_profile_json returns {"family": {"launches": n, "ms": t}, ...} accumulated since enable. */
+int ira_profile_enable(ira_model_t* model, int on);
+const char* ira_profile_json(ira_model_t* model);
+
+/* Bytes of device memory currently held by the model (weights + workspace). */
+int ira_memory_bytes(ira_model_t* model, size_t* bytes);
+
+/* ------------------------------------------------------------------ single-kernel entry points
+ * Used by the parity tests (tests/test_gpu_ops.py) to check each hand-written kernel against the
+ * oracle in isolation.  Device pointers; shapes as documented in DESIGN.md "Kernels".
+ * T = number of tiles, P = pixels per tile (H*W). */
+
+/* y[T*P][n_store] (fp16) = LN_mode(x)[T*P][K] @ W[NB*32][K]^T (+ bias).  x is fp32 (in_f32=1) or fp16.
+ * ln_mode: 0 none, 1 BiasFree core (x*rstd), 2 WithBias core ((x-mu)*rstd); LN gain/bias are folded
+ * into W/bias by the packer.  (restormer_arch.py:37-39,54-57 + the 1x1 convs :82,105) */
+int ira_op_pw_kres(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K,
+                   const void* W_f16_dev, const float* bias_dev, void* y_f16_dev, int y_stride,
+                   int n_store, int NB, int T, int P);
+
+/* y[T*P][N] (fp32) = [x0|x1][T*P][K0+K1] @ W^T (+bias) (+resid).  W is [NB*32][K0+K1] fp16, shared
+ * (w_tile_stride = 0) or one matrix per tile (elements between consecutive tiles' matrices).
+ * (project_out + residual :131,92,148-149; reduce_chan :223,228; attention apply) */
+int ira_op_pw_nres(ira_model_t* m, const void* x0_dev, int K0, const void* x1_dev, int K1, int in_f32,
+                   const void* W_f16_dev, long w_tile_stride, const float* bias_dev,
+                   const float* resid_dev, float* y_dev, int N, int NB, int T, int P);
+
+/* Depthwise 3x3 (zero pad) on qkv (restormer_arch.py:106,114): in fp16 NHWC (T,H,W,3C), w fp32 [9][3C],
+ * bias fp32 [3C] or NULL.  q,k -> fp16 "pixel-minor" (T,H,ceil(W/8),2C,8); v -> fp16 NHWC (T,H,W,C). */
+int ira_op_dwconv_qkv(ira_model_t* m, const void* in_dev, const float* w_dev, const float* bias_dev,
+                      void* qk_dev, void* v_dev, int T, int H, int W, int C);
+
+/* Depthwise 3x3 + GELU gate (restormer_arch.py:84,90-91): in fp16 NHWC (T,H,W,2*Hp), out fp16 (T,H,W,Hp),
+ * out = gelu(dw(in[:Hp])) * dw(in[Hp:]). */
+int ira_op_dwconv_gate(ira_model_t* m, const void* in_dev, const float* w_dev, const float* bias_dev,
+                       void* out_dev, int T, int H, int W, int Hp);
+
+/* Partial Gram + squared norms (restormer_arch.py:121-124): qk pixel-minor as above ->
+ * part fp32 [T][S][heads][c*c + 2c]  (c = C/heads; gram row-major [q ch][k ch], then |q|^2, |k|^2). */
+int ira_op_gram(ira_model_t* m, const void* qk_dev, float* part_dev, int T, int nblk, int C, int heads, int S);
+
+/* M[t] = W_o . blockdiag_h(softmax(gram / (|q||k|) * temperature))  -> fp16 [T][NB*32][C]
+ * (restormer_arch.py:121-131 re-associated; DESIGN.md "attention as a per-tile 1x1"). */
+int ira_op_attn_mix(ira_model_t* m, const float* part_dev, const float* wo_dev, const float* temp_dev,
+                    void* M_f16_dev, int T, int C, int heads, int S, int NB);
+
+/* Dense 3x3 conv, zero pad, fp32 NHWC in (T,H,W,K) -> fp32 out.  W fp16 [9][NB*32][K].
+ * mode 0: plain (T,H,W,N); 1: + PixelUnshuffle(2) -> (T,H/2,W/2,4N)  (restormer_arch.py:171-179);
+ * 2: + PixelShuffle(2) -> (T,2H,2W,N/4) (:181-189); 3: final conv + input skip (:281), skip fp32 (T,H,W,N). */
+int ira_op_conv3x3(ira_model_t* m, const float* in_dev, const void* W_f16_dev, const float* bias_dev,
+                   const float* skip_dev, float* out_dev, int mode, int T, int H, int W, int K, int N, int NB);
+
+/* patch_embed (restormer_arch.py:156-165): fp32 NHWC (T,H,W,ic) -> fp32 (T,H,W,C), W fp32 [C][ic][3][3]. */
+int ira_op_embed(ira_model_t* m, const float* in_dev, const float* w_dev, const float* bias_dev,
+                 float* out_dev, int T, int H, int W, int ic, int C);
+
+/* torch.cat([a, b], 1) on fp32 NHWC (restormer_arch.py:270). */
+int ira_op_concat2(ira_model_t* m, const float* a_dev, int Ca, const float* b_dev, int Cb, float* out_dev, long npx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRA_H */

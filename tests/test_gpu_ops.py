@@ -1,0 +1,287 @@
+"""Per-kernel parity on a real MI355X: every hand-written HIP kernel, called through the C ABI
+(include/ira.h, ira_op_*), against a plain torch CPU fp32 statement of the same op on the same
+(fp16-rounded) inputs.  Reference ops: restormer_arch.py (cited per test).
+
+Tolerances: outputs stored as fp16 are compared with rtol 2e-3 (fp16 has 2^-11 relative spacing,
+MFMA accumulates in fp32 in a different order than the CPU); fp32 outputs with rtol 1e-3 because the
+MFMA operands are fp16-rounded identically on both sides and only the summation order differs.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def r16(t):
+    return t.half().float()
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from ira_amd.backend import RestormerBackend
+    from ira_amd.config import reduced_config
+    from ira_amd.weights import seeded_state_dict
+    cfg = reduced_config('BiasFree')
+    be = RestormerBackend(cfg, seeded_state_dict(cfg, 1), device=0)
+    yield be
+    be.close()
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rowperm_pad(w, rows):
+    out = torch.zeros(rows, w.shape[1], dtype=w.dtype)
+    out[:w.shape[0]] = w
+    return out
+
+
+def up32(n):
+    return (n + 31) // 32 * 32
+
+
+def close(a, b, rtol, atol_scale=1e-3):
+    a = a.double(); b = b.double()
+    atol = atol_scale * float(b.abs().max()) + 1e-6
+    err = (a - b).abs()
+    bad = err > (atol + rtol * b.abs())
+    assert not bad.any(), f"max err {float(err.max()):.3e} (ref max {float(b.abs().max()):.3e}), {int(bad.sum())}/{bad.numel()} bad"
+
+
+def ln_core(x, mode):
+    if mode == 0:
+        return x
+    mu = x.mean(-1, keepdim=True)
+    var = x.var(-1, keepdim=True, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    return x * rstd if mode == 1 else (x - mu) * rstd
+
+
+@pytest.mark.parametrize('K,N,ln,in_f32,T,P,with_bias', [
+    (48, 144, 1, True, 2, 77, False),      # LN(BiasFree)+qkv at level 1 (restormer_arch.py:37-39,105)
+    (96, 512, 2, True, 1, 64, True),       # LN(WithBias)+project_in, padded hidden 255->256 (:54-57,82)
+    (16, 48, 1, True, 3, 33, False),       # reduced config
+    (384, 1152, 1, True, 1, 40, False),    # latent level
+    (192, 576, 2, True, 2, 31, True),
+    (128, 64, 0, False, 2, 50, False),     # fp16 input, no LN
+    (32, 96, 0, True, 1, 5, True),
+])
+def test_pw_kres(ctx, K, N, ln, in_f32, T, P, with_bias):
+    g = torch.Generator().manual_seed(K * 7 + N)
+    x = torch.randn(T * P, K, generator=g) * 1.7 + 0.3
+    if not in_f32:
+        x = r16(x)
+    NB = up32(N) // 32
+    W = r16(torch.randn(N, K, generator=g) / K ** 0.5)
+    Wp = rowperm_pad(W, NB * 32)
+    bias = torch.randn(NB * 32, generator=g) * 0.1 if with_bias else None
+    ref = r16(ln_core(x, ln)) @ W.t()
+    if with_bias:
+        ref = ref + bias[:N]
+    y = torch.full((T * P, N), float('nan'), dtype=torch.float16).cuda()
+    xd = dev(x if in_f32 else x.half())
+    Wd = dev(Wp.half())
+    bd = dev(bias) if with_bias else None
+    rc = ctx._lib.ira_op_pw_kres(ctx.handle, ptr(xd), int(in_f32), ln, K, ptr(Wd), ptr(bd), ptr(y), N, N, NB, T, P)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu().float(), ref, 2e-3)
+
+
+@pytest.mark.parametrize('K0,K1,in_f32,N,T,P,resid,per_tile,with_bias', [
+    (96, 0, False, 96, 2, 70, True, True, False),     # attention apply: per-tile M on V + residual
+    (256, 0, False, 48, 2, 45, True, False, False),   # project_out + residual (:92,149), Hp=128*2
+    (192, 192, True, 192, 1, 64, False, False, True),  # reduce_chan on cat (:260-261)
+    (64, 0, False, 16, 3, 9, True, False, False),     # reduced
+    (1024, 0, False, 384, 1, 33, True, False, False),  # latent project_out
+    (48, 48, True, 48, 2, 31, False, False, False),
+])
+def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
+    g = torch.Generator().manual_seed(K0 + 3 * N + K1)
+    K = K0 + K1
+    NB = up32(N) // 32
+    x0 = torch.randn(T * P, K0, generator=g)
+    x1 = torch.randn(T * P, K1, generator=g) if K1 else None
+    if not in_f32:
+        x0 = r16(x0)
+    nW = T if per_tile else 1
+    W = r16(torch.randn(nW, N, K, generator=g) / K ** 0.5)
+    Wp = torch.zeros(nW, NB * 32, K); Wp[:, :N] = W
+    bias = torch.randn(NB * 32, generator=g) * 0.1 if with_bias else None
+    res = torch.randn(T * P, N, generator=g) if resid else None
+    xin = torch.cat([x0, x1], 1) if K1 else x0
+    xin16 = r16(xin).view(T, P, K)
+    ref = torch.einsum('tpk,tnk->tpn', xin16, W.expand(T, -1, -1) if not per_tile else W).reshape(T * P, N)
+    if with_bias:
+        ref = ref + bias[:N]
+    if resid:
+        ref = ref + res
+    y = dev(res.clone()) if resid else torch.full((T * P, N), float('nan')).cuda()
+    x0d = dev(x0 if in_f32 else x0.half())
+    x1d = dev(x1) if K1 else None
+    Wd = dev(Wp.half())
+    bd = dev(bias) if with_bias else None
+    rc = ctx._lib.ira_op_pw_nres(ctx.handle, ptr(x0d), K0, ptr(x1d), K1, int(in_f32), ptr(Wd),
+                                 NB * 32 * K if per_tile else 0, ptr(bd), ptr(y) if resid else None, ptr(y),
+                                 N, NB, T, P)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), ref, 1e-3)
+
+
+def px_minor(t_nchw):
+    """(T,Cq,H,W) -> (T,H,WB,Cq,8) zero-padded along W."""
+    T, Cq, H, W = t_nchw.shape
+    WB = (W + 7) // 8
+    pad = torch.zeros(T, Cq, H, WB * 8)
+    pad[..., :W] = t_nchw
+    return pad.view(T, Cq, H, WB, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+@pytest.mark.parametrize('C,T,H,W', [(16, 2, 5, 13), (48, 1, 8, 16), (96, 1, 3, 7)])
+def test_dwconv_qkv(ctx, C, T, H, W):
+    g = torch.Generator().manual_seed(C + H)
+    x = r16(torch.randn(T, 3 * C, H, W, generator=g))
+    w = torch.randn(3 * C, 1, 3, 3, generator=g) / 3
+    ref = F.conv2d(x, w, padding=1, groups=3 * C)          # restormer_arch.py:106,114
+    q_ref = px_minor(ref[:, :2 * C])
+    v_ref = ref[:, 2 * C:].permute(0, 2, 3, 1).contiguous()
+    xd = dev(x.permute(0, 2, 3, 1).half())
+    wd = dev(w.view(3 * C, 9).t())
+    WB = (W + 7) // 8
+    qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
+    v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
+    rc = ctx._lib.ira_op_dwconv_qkv(ctx.handle, ptr(xd), ptr(wd), None, ptr(qk), ptr(v), T, H, W, C)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(v.cpu().float(), v_ref, 2e-3)
+    close(qk.cpu().float(), q_ref, 2e-3)
+
+
+@pytest.mark.parametrize('Hp,T,H,W', [(64, 2, 6, 9), (128, 1, 4, 24), (32, 1, 2, 3)])
+def test_dwconv_gate(ctx, Hp, T, H, W):
+    g = torch.Generator().manual_seed(Hp + W)
+    x = r16(torch.randn(T, 2 * Hp, H, W, generator=g))
+    w = torch.randn(2 * Hp, 1, 3, 3, generator=g) / 3
+    d = F.conv2d(x, w, padding=1, groups=2 * Hp)            # restormer_arch.py:84,90
+    ref = (F.gelu(d[:, :Hp]) * d[:, Hp:]).permute(0, 2, 3, 1).contiguous()   # :91
+    xd = dev(x.permute(0, 2, 3, 1).half())
+    wd = dev(w.view(2 * Hp, 9).t())
+    out = torch.full((T, H, W, Hp), float('nan'), dtype=torch.float16).cuda()
+    rc = ctx._lib.ira_op_dwconv_gate(ctx.handle, ptr(xd), ptr(wd), None, ptr(out), T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(out.cpu().float(), ref, 2e-3)
+
+
+@pytest.mark.parametrize('C,heads,T,H,W,S', [(96, 1, 2, 6, 20, 3), (96, 2, 1, 9, 16, 2), (32, 2, 2, 4, 5, 1),
+                                             (32, 1, 1, 7, 9, 4), (384, 8, 1, 3, 8, 2)])
+def test_gram(ctx, C, heads, T, H, W, S):
+    g = torch.Generator().manual_seed(C + heads + W)
+    c = C // heads
+    qk = r16(torch.randn(T, 2 * C, H, W, generator=g))
+    qkd = dev(px_minor(qk).half())
+    nblk = H * ((W + 7) // 8)
+    rec = c * c + 2 * c
+    part = torch.full((T, S, heads, rec), float('nan')).cuda()
+    rc = ctx._lib.ira_op_gram(ctx.handle, ptr(qkd), ptr(part), T, nblk, C, heads, S)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    got = part.cpu().sum(1)                                   # (T, heads, rec)
+    q = qk[:, :C].reshape(T, heads, c, H * W)
+    k = qk[:, C:].reshape(T, heads, c, H * W)
+    gram = q @ k.transpose(-1, -2)                            # restormer_arch.py:124
+    close(got[..., :c * c].reshape(T, heads, c, c), gram, 1e-3)
+    close(got[..., c * c:c * c + c], q.pow(2).sum(-1), 1e-3)
+    close(got[..., c * c + c:], k.pow(2).sum(-1), 1e-3)
+
+
+@pytest.mark.parametrize('C,heads,T,S', [(96, 1, 2, 3), (96, 2, 1, 1), (48, 1, 2, 2), (32, 2, 1, 2), (128, 8, 2, 1)])
+def test_attn_mix(ctx, C, heads, T, S):
+    g = torch.Generator().manual_seed(C * heads + S)
+    c = C // heads
+    n = 500
+    q = torch.randn(T, heads, c, n, generator=g)
+    k = torch.randn(T, heads, c, n, generator=g) + 0.5 * q
+    gram = q @ k.transpose(-1, -2)
+    nq, nk = q.pow(2).sum(-1), k.pow(2).sum(-1)
+    full = torch.cat([gram.reshape(T, heads, c * c), nq, nk], -1)       # (T, heads, rec)
+    wts = torch.rand(S, generator=g) + 0.1
+    wts = wts / wts.sum()
+    part = torch.stack([full * wts[s] for s in range(S)], 1).contiguous()   # (T,S,heads,rec)
+    wo = torch.randn(C, C, generator=g) / C ** 0.5
+    temp = torch.rand(heads, generator=g) * 5 + 1
+    # reference: restormer_arch.py:121-131 re-associated
+    logits = gram / (nq.sqrt().clamp_min(1e-12).unsqueeze(-1) * nk.sqrt().clamp_min(1e-12).unsqueeze(-2))
+    attn = (logits * temp.view(1, heads, 1, 1)).softmax(-1)
+    ref = torch.einsum('ohi,thij->tohj', wo.view(C, heads, c), attn).reshape(T, C, C)
+    NB = up32(C) // 32
+    M = torch.zeros(T, NB * 32, C, dtype=torch.float16).cuda()
+    rc = ctx._lib.ira_op_attn_mix(ctx.handle, ptr(dev(part)), ptr(dev(wo)), ptr(dev(temp)), ptr(M), T, C, heads, S, NB)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(M.cpu().float()[:, :C], ref, 2e-3)
+
+
+def conv3_pack(w):
+    n, k = w.shape[:2]
+    out = torch.zeros(9, up32(n), k)
+    out[:, :n] = w.reshape(n, k, 9).permute(2, 0, 1)
+    return out.half()
+
+
+@pytest.mark.parametrize('mode,K,N,T,H,W', [
+    (0, 32, 40, 1, 5, 7),
+    (1, 48, 24, 2, 6, 10),     # Downsample: conv + PixelUnshuffle (restormer_arch.py:171-179)
+    (1, 192, 96, 1, 4, 4),
+    (2, 32, 64, 2, 3, 5),      # Upsample: conv + PixelShuffle (:181-189)
+    (2, 384, 768, 1, 2, 3),
+    (2, 64, 256, 1, 4, 4),     # NB=8: two n-chunks, the second partial
+    (3, 96, 3, 2, 8, 9),       # output conv + input skip (:281)
+    (3, 32, 1, 1, 5, 5),
+])
+def test_conv3x3(ctx, mode, K, N, T, H, W):
+    g = torch.Generator().manual_seed(mode * 100 + K + N)
+    x = torch.randn(T, K, H, W, generator=g)
+    w = r16(torch.randn(N, K, 3, 3, generator=g) / (9 * K) ** 0.5)
+    y = F.conv2d(r16(x), w, padding=1)
+    skip = None
+    if mode == 1:
+        y = F.pixel_unshuffle(y, 2)
+    elif mode == 2:
+        y = F.pixel_shuffle(y, 2)
+    elif mode == 3:
+        skip = torch.randn(T, N, H, W, generator=g)
+        y = y + skip
+    ref = y.permute(0, 2, 3, 1).contiguous()
+    out = torch.full(ref.shape, float('nan')).cuda()
+    xd = dev(x.permute(0, 2, 3, 1))
+    sd = dev(skip.permute(0, 2, 3, 1)) if skip is not None else None
+    NB = up32(N) // 32
+    rc = ctx._lib.ira_op_conv3x3(ctx.handle, ptr(xd), ptr(dev(conv3_pack(w))), None, ptr(sd), ptr(out), mode, T, H, W, K, N, NB)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(out.cpu(), ref, 1e-3)
+
+
+@pytest.mark.parametrize('ic,Cc,T,H,W', [(3, 48, 2, 5, 9), (1, 16, 1, 8, 8)])
+def test_embed(ctx, ic, Cc, T, H, W):
+    g = torch.Generator().manual_seed(ic + Cc)
+    x = torch.rand(T, ic, H, W, generator=g)
+    w = torch.randn(Cc, ic, 3, 3, generator=g) / (9 * ic) ** 0.5
+    ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1).contiguous()      # restormer_arch.py:156-165
+    out = torch.full(ref.shape, float('nan')).cuda()
+    rc = ctx._lib.ira_op_embed(ctx.handle, ptr(dev(x.permute(0, 2, 3, 1))), ptr(dev(w)), None, ptr(out), T, H, W, ic, Cc)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(out.cpu(), ref, 1e-5, 1e-6)
+
+
+def test_concat2(ctx):
+    a = torch.randn(37, 48)
+    b = torch.randn(37, 16)
+    out = torch.zeros(37, 64).cuda()
+    rc = ctx._lib.ira_op_concat2(ctx.handle, ptr(dev(a)), 48, ptr(dev(b)), 16, ptr(out), 37)
+    assert rc == 0
+    assert torch.equal(out.cpu(), torch.cat([a, b], 1))     # restormer_arch.py:270
