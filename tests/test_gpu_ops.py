@@ -221,7 +221,8 @@ def test_attn_mix(ctx, C, heads, T, S):
     ref = torch.einsum('ohi,thij->tohj', wo.view(C, heads, c), attn).reshape(T, C, C)
     NB = up32(C) // 32
     M = torch.zeros(T, NB * 32, C, dtype=torch.float16).cuda()
-    rc = ctx._lib.ira_op_attn_mix(ctx.handle, ptr(dev(part)), ptr(dev(wo)), ptr(dev(temp)), ptr(M), T, C, heads, S, NB)
+    pd, wod, td = dev(part), dev(wo), dev(temp)     # keep the device tensors alive across the call
+    rc = ctx._lib.ira_op_attn_mix(ctx.handle, ptr(pd), ptr(wod), ptr(td), ptr(M), T, C, heads, S, NB)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(M.cpu().float()[:, :C], ref, 2e-3)
 
@@ -261,7 +262,8 @@ def test_conv3x3(ctx, mode, K, N, T, H, W):
     xd = dev(x.permute(0, 2, 3, 1))
     sd = dev(skip.permute(0, 2, 3, 1)) if skip is not None else None
     NB = up32(N) // 32
-    rc = ctx._lib.ira_op_conv3x3(ctx.handle, ptr(xd), ptr(dev(conv3_pack(w))), None, ptr(sd), ptr(out), mode, T, H, W, K, N, NB)
+    wd = dev(conv3_pack(w))
+    rc = ctx._lib.ira_op_conv3x3(ctx.handle, ptr(xd), ptr(wd), None, ptr(sd), ptr(out), mode, T, H, W, K, N, NB)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(out.cpu(), ref, 1e-3)
 
@@ -273,7 +275,8 @@ def test_embed(ctx, ic, Cc, T, H, W):
     w = torch.randn(Cc, ic, 3, 3, generator=g) / (9 * ic) ** 0.5
     ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1).contiguous()      # restormer_arch.py:156-165
     out = torch.full(ref.shape, float('nan')).cuda()
-    rc = ctx._lib.ira_op_embed(ctx.handle, ptr(dev(x.permute(0, 2, 3, 1))), ptr(dev(w)), None, ptr(out), T, H, W, ic, Cc)
+    xd, wd = dev(x.permute(0, 2, 3, 1)), dev(w)
+    rc = ctx._lib.ira_op_embed(ctx.handle, ptr(xd), ptr(wd), None, ptr(out), T, H, W, ic, Cc)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(out.cpu(), ref, 1e-5, 1e-6)
 
@@ -282,6 +285,7 @@ def test_concat2(ctx):
     a = torch.randn(37, 48)
     b = torch.randn(37, 16)
     out = torch.zeros(37, 64).cuda()
-    rc = ctx._lib.ira_op_concat2(ctx.handle, ptr(dev(a)), 48, ptr(dev(b)), 16, ptr(out), 37)
+    ad, bd = dev(a), dev(b)
+    rc = ctx._lib.ira_op_concat2(ctx.handle, ptr(ad), 48, ptr(bd), 16, ptr(out), 37)
     assert rc == 0
     assert torch.equal(out.cpu(), torch.cat([a, b], 1))     # restormer_arch.py:270
