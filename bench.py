@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: restored megapixels/s at 4K, Restormer-denoise, tile-parallel (BASELINE.json).
+
+One step = one 3840x2160 uint8 frame, already resident in HBM, through the reference harness
+semantics (demo.py:120-161): 40 overlapping 512x512 tiles (overlap 32) -> batched Restormer forward ->
+(N > 1: RCCL all-gather of the restored tiles) -> E/W overlap average -> clamp -> uint8, output left
+in HBM.  N ranks share the tile list of the SAME frame (strong scaling: total work per step is fixed).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'image-restoration-agent_amd'))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense
+
+
+def algorithmic_elements_per_px(cfg):
+    """SURVEY 8d fusion contract: 14C + 6Hf elements per level-pixel per TransformerBlock, summed with
+    the level down-sampling, + 513 glue elements (embed, down/up, reduce, output+skip) for the default
+    architecture (scaled by dim/48 otherwise).  Default Restormer: 43 612 elements per tile pixel."""
+    d, nb = cfg.dim, cfg.num_blocks
+    tot = 0.0
+    for lvl, (c, n) in enumerate([(d, nb[0]), (2 * d, nb[1] * 2), (4 * d, nb[2] * 2), (8 * d, nb[3])]):
+        tot += n * (14 * c + 6 * cfg.hidden(c)) / (4 ** lvl)
+    tot += (nb[0] + cfg.num_refinement_blocks) * (14 * 2 * d + 6 * cfg.hidden(2 * d))
+    return tot + 513.0 * d / 48.0
+
+
+def family_elements(family, C, Hf):
+    """Algorithmic elements per level-pixel of one kernel family (groups G1..G6 of SURVEY 8d)."""
+    return {
+        'ln_qkv_1x1': 4 * C,          # G1: read C, write 3C
+        'dwconv_qkv': 4 * C,          # G2: read 3C, write C (only V is stored in the contract)
+        'gram': 0,                    # inside G2 in the contract: any traffic here is overhead
+        'attn_mix': 0,
+        'attn_apply_res': 3 * C,      # G3: read C + C, write C
+        'ln_pin_1x1': C + 2 * Hf,     # G4
+        'dwconv_gate': 3 * Hf,        # G5: read 2Hf, write Hf
+        'pout_res': Hf + 2 * C,       # G6
+    }.get(family, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--height', type=int, default=2160)
+    ap.add_argument('--width', type=int, default=3840)
+    ap.add_argument('--tile', type=int, default=512)
+    ap.add_argument('--overlap', type=int, default=32)
+    ap.add_argument('--batch', type=int, default=0, help='max tiles per network launch (0 = library default)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from ira_amd import _capi
+    from ira_amd.backend import RestormerBackend
+    from ira_amd.config import task_config
+    from ira_amd.dist import TileParallelRestorer
+    from ira_amd.synth import synthetic_noisy_image
+    from ira_amd.weights import seeded_state_dict
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    cfg = task_config('Real_Denoising')          # LayerNorm BiasFree, demo.py:59-61
+    be = RestormerBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
+    if args.batch:
+        be.set_max_batch(args.batch)
+    h, w = args.height, args.width
+    clean, noisy = synthetic_noisy_image(h, w, 3, sigma=25.0, seed=0)
+    frame = torch.from_numpy(noisy).to(dev)
+    out = torch.empty_like(frame)
+    Hp, Wp, th, tw, n_rows, n_cols = _capi.tile_plan(h, w, args.tile, args.overlap)
+    n_tiles = n_rows * n_cols
+    rst = TileParallelRestorer(be, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        be.sync()
+
+    for _ in range(args.warmup):
+        rst.restore_frame(frame, args.tile, args.overlap, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    be.timer_start()
+    for _ in range(args.steps):
+        rst.restore_frame(frame, args.tile, args.overlap, out=out)
+    dev_ms = be.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    result = None
+    if rank == 0:
+        mp_out = h * w / 1e6
+        value = mp_out * args.steps / elapsed
+        computed_px = n_tiles * th * tw
+        el_px = algorithmic_elements_per_px(cfg)
+        net_bytes = el_px * 2.0 * computed_px                       # fp16 contract, per step (all ranks)
+        result = {
+            'metric': 'restored megapixels/sec at 4K (Restormer-denoise)', 'value': round(value, 4), 'unit': 'MP/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic',
+            'config': {'workload': f'Restormer Real_Denoising (BiasFree LN, 26.1M params, seeded weights), {w}x{h} uint8 frame, '
+                                   f'tile {th} overlap {args.overlap} -> {n_tiles} tiles ({computed_px / 1e6:.2f} MP computed), '
+                                   f'tile-parallel over {world} GPU(s)',
+                       'frames_per_s': round(value / mp_out, 4), 'tiles': n_tiles,
+                       'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
+            'net_roofline': {'bound': 'hbm', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
+                             'achieved': round(net_bytes / 1e9 / (elapsed / args.steps) / world, 1), 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s per GPU', 'frac': round(net_bytes / 1e9 / (elapsed / args.steps) / world / HBM_PEAK_GBS, 4)},
+        }
+
+    # ---- roofline of the dominant kernel: live HIP-event timing of every launch of one extra step
+    if world == 1 and not args.no_kernel_profile:
+        be.profile_enable(True)
+        rst.restore_frame(frame, args.tile, args.overlap, out=out)
+        prof = be.profile()
+        be.profile_enable(False)
+        tot = sum(v['ms'] for v in prof.values())
+        fam_tot = {}
+        for k, v in prof.items():
+            fam_tot[k.split('|')[0]] = fam_tot.get(k.split('|')[0], 0.0) + v['ms']
+        key = max(prof, key=lambda k: prof[k]['ms'])
+        parts = key.split('|')
+        roof = {'bound': 'hbm', 'kernel': key, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
+        if len(parts) == 4:
+            fam, C = parts[0], int(parts[1][1:])
+            Hh, Ww = (int(v) for v in parts[2].split('x'))
+            T = int(parts[3][1:])
+            alg = family_elements(fam, C, cfg.hidden(C)) * 2.0 * T * Hh * Ww
+            avg_ms = prof[key]['ms'] / prof[key]['launches']
+            roof.update({'achieved': round(alg / 1e9 / (avg_ms / 1e3), 1), 'avg_launch_ms': round(avg_ms, 4),
+                         'launches_per_step': prof[key]['launches'], 'algorithmic_bytes_per_launch': int(alg),
+                         'share_of_step': round(prof[key]['ms'] / tot, 4)})
+            roof['frac'] = round(roof['achieved'] / HBM_PEAK_GBS, 4)
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # PMC bytes per launch, measured offline
+            if os.path.exists(tpath):
+                try:
+                    roof['traffic'] = json.load(open(tpath)).get(key)
+                except Exception:
+                    roof['traffic'] = None
+        result['roofline'] = roof
+        result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
+        result['kernel_ms_total_profiled'] = round(tot, 3)
+    elif rank == 0:
+        result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+                              'traffic': None, 'note': 'per-kernel timing is collected at N=1 only'}
+
+    # ---- CPU baseline: the oracle (torch CPU fp32 restatement of the reference) on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import restormer_oracle as O
+        from ira_amd.weights import to_torch
+        cores = min(16, os.cpu_count() or 1)          # one-GPU box share
+        torch.set_num_threads(cores)
+        sd = to_torch(seeded_state_dict(cfg, 0))
+        S = 256
+        x = torch.from_numpy(noisy[:S, :S]).float().div(255.).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            O.restormer_forward(x, sd, cfg.to_dict())
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                y = O.restormer_forward(x, sd, cfg.to_dict())
+            dt = (time.perf_counter() - t1) / reps
+        tile_mps = S * S / 1e6 / dt
+        result['cpu_baseline'] = {
+            'value': round(tile_mps * (h * w) / computed_px, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/restormer_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {S}x{S} tile '
+                      f'after 1 warm-up ({dt:.2f} s each = {tile_mps:.5f} computed MP/s); value = that rate x output/computed '
+                      f'pixel ratio {h * w / computed_px:.4f} of the 4K tiling'}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -274,21 +274,28 @@ int ensure_scratch(ira_model* m, size_t bytes) {
 // ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
 int run_block(ira_model* m, const Blk& b, float* x, int T, int H, int W, int C, int heads, int Hp) {
     const int P = H * W;
+    char k_[8][64];
+    if (m->profile) {
+        const char* fam[8] = {"ln_qkv_1x1", "dwconv_qkv", "gram", "attn_mix", "attn_apply_res", "ln_pin_1x1", "dwconv_gate", "pout_res"};
+        for (int i = 0; i < 8; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
+    } else {
+        for (int i = 0; i < 8; ++i) k_[i][0] = 0;
+    }
     const int ln = m->cfg.ln_with_bias ? 2 : 1;
     const int NBq = up32(3 * C) / 32, NBc = up32(C) / 32;
     const long nblk = (long)H * ((W + 7) / 8);
     const int S = gram_splits(T, heads, nblk);
     hipStream_t st = m->st;
     // MDTA (:111-132)
-    RUN(m, "ln_qkv_1x1", ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
-    RUN(m, "dwconv_qkv", ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
-    RUN(m, "gram", ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-    RUN(m, "attn_mix", ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->M, T, C, heads, S, NBc));
-    RUN(m, "attn_apply_res", ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, (long)NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
+    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
+    RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
+    RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
+    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->M, T, C, heads, S, NBc));
+    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, (long)NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
     // GDFN (:88-93)
-    RUN(m, "ln_pin_1x1", ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
-    RUN(m, "dwconv_gate", ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
-    RUN(m, "pout_res", ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
+    RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
+    RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
+    RUN(m, k_[7], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
     return IRA_OK;
 }
 

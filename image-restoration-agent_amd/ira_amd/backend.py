@@ -114,6 +114,15 @@ class RestormerBackend:
         rc = self._lib.ira_blend_tiles_device(self._h, tiles_ptr, h, w, c, int(tile) if tile else 0, int(overlap), out_ptr)
         self._ck(rc, 'ira_blend_tiles_device')
 
+    # tensor-taking forms used by ira_amd.dist (torch is plumbing: device memory only)
+    def restore_tiles_t(self, frame, h, w, c, tile, overlap, first_tile, n_tiles, out):
+        assert frame.is_cuda and out.is_cuda and frame.is_contiguous() and out.is_contiguous()
+        self.restore_tiles_device(frame.data_ptr(), h, w, c, tile, overlap, first_tile, n_tiles, out.data_ptr())
+
+    def blend_tiles_t(self, tiles, h, w, c, tile, overlap, out):
+        assert tiles.is_cuda and out.is_cuda and tiles.is_contiguous() and out.is_contiguous()
+        self.blend_tiles_device(tiles.data_ptr(), h, w, c, tile, overlap, out.data_ptr())
+
     # -- measurement
     def set_max_batch(self, n: int):
         self._ck(self._lib.ira_set_max_batch(self._h, int(n)), 'ira_set_max_batch')
