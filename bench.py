@@ -64,6 +64,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='max tiles per network launch (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--profile-out', default='', help='write the per-kernel HIP-event profile (JSON) here')
     args = ap.parse_args()
 
     import numpy as np
@@ -149,6 +150,9 @@ def main():
         rst.restore_frame(frame, args.tile, args.overlap, out=out)
         prof = be.profile()
         be.profile_enable(False)
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f, indent=1, sort_keys=True)
         tot = sum(v['ms'] for v in prof.values())
         fam_tot = {}
         for k, v in prof.items():

@@ -24,8 +24,9 @@ hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, co
 
 hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int nblk, int C, int heads, int S);
 
+// attn_scratch: fp32 [T][heads][c][c]
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
-                           void* M, int T, int C, int heads, int S, int NB);
+                           float* attn_scratch, void* M, int T, int C, int heads, int S, int NB);
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);

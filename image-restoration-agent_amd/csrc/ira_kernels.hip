@@ -7,6 +7,10 @@
 //   branch activations     fp16 NHWC  (qkv_pre, v, hidden_pre, gated hidden)
 //   q,k after the dwconv   fp16 "pixel-minor" [T][H][ceil(W/8)][2C][8]   (K-dim of the Gram = pixels)
 //   all contractions       v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fp32 accumulate
+//   weights                fp16 hi + fp16 lo planes (W ~= hi + lo to ~2^-22): every weight MFMA is issued
+//                          twice on the same pixel fragment.  A fixed weight-rounding error does not
+//                          average out over pixels, and it was the largest term in the 1e-3 dB PSNR
+//                          budget (DESIGN.md "Numerics contract")
 //   LN statistics, dwconv, softmax, GELU, residual adds: fp32 VALU
 //
 // MFMA operand convention used by every 1x1 / 3x3 conv here ("weights are A, pixels are B"):
@@ -19,6 +23,8 @@
 //      channels of ITS pixel -> 16/32-byte NHWC stores, and the registers are already the B fragment
 //      (k = 16s + 8h + j) of a following MFMA that contracts over these channels.
 #include "ira_kernels.h"
+
+#include <cstdlib>
 
 namespace ira {
 
@@ -42,7 +48,20 @@ IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; re
 
 IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
 
-IRA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU (F.gelu default, restormer_arch.py:91): 0.5 x (1 + erf(x / sqrt 2)).
+// erfc(|z|) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), used as 1+erf(z) = erfc(-z) so that the
+// negative tail has no cancellation; branch-free: one v_rcp, one v_exp, six FMAs.
+IRA_DEV float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = p * t * __expf(-z * z);            // erfc(|z|)
+    const float one_plus_erf = (x >= 0.f) ? (2.0f - e) : e;
+    return 0.5f * x * one_plus_erf;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Pointwise (1x1) conv, "K-resident": all K input channels of the wave's 32 pixels stay in
@@ -51,99 +70,120 @@ IRA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.707106781
 //   x: [T*P][K] fp32 or fp16.   W: [NB*32][K] fp16 (rows >= N zero).   y: [T*P][y_stride] fp16.
 // LN: 0 none; 1 BiasFree core x*rsqrt(var+1e-5) (:37-39); 2 WithBias core (x-mu)*rsqrt(var+1e-5)
 // (:54-57). The gain (and W@ln_bias) are folded into W / bias by the packer.
-template <int KS, int LN, bool IN_F32>
+// PG = 32-pixel groups per wave: every A (weight) fragment fetched from L1/L2 is reused on PG pixel
+// groups, which divides the weight traffic per pixel by PG (at PG = 1 it exceeded the HBM traffic 4x).
+template <int KS, int LN, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, f16* __restrict__ y,
                                                  int y_stride, int n_store, int NB, int T, int P) {
+    // W: [2][NB*32][K]  (hi plane, lo plane)
     constexpr int K = KS * 16;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int chunks = (P + 31) >> 5;
+    const int chunks = (P + 32 * PG - 1) / (32 * PG);
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= (long)T * chunks) return;
     const int t = (int)(wv / chunks);
-    const int p = (int)(wv % chunks) * 32 + r;
-    const bool valid = p < P;
-    const long px = (long)t * P + (valid ? p : P - 1);
+    const int pbase = (int)(wv % chunks) * 32 * PG + r;
 
-    half8 b[KS];
-    if constexpr (IN_F32) {
-        const float* src = (const float*)xin + px * K + 8 * h;
-        float xv[KS][8];
+    half8 b[PG][KS];
+    bool valid[PG];
+    long px[PG];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 lo = *(const f32x4*)(src + 16 * s);
-            const f32x4 hi = *(const f32x4*)(src + 16 * s + 4);
+    for (int g = 0; g < PG; ++g) {
+        const int p = pbase + 32 * g;
+        valid[g] = p < P;
+        px[g] = (long)t * P + (valid[g] ? p : P - 1);
+        if constexpr (IN_F32) {
+            const float* src = (const float*)xin + px[g] * K + 8 * h;
+            float xv[KS][8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s);
+                const f32x4 hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+            }
+            if constexpr (LN != 0) {
+                float sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += xv[s][j];
+                sum += __shfl_xor(sum, 32);
+                const float mu = sum * (1.0f / K);
+                float sq = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+                sq += __shfl_xor(sq, 32);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f);
+                const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[s][j] = (xv[s][j] - sub) * rstd;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[g][s][j] = (f16)xv[s][j];
+        } else {
+            const f16* src = (const f16*)xin + px[g] * K + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[g][s] = *(const half8*)(src + 16 * s);
         }
-        if constexpr (LN != 0) {
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum += xv[s][j];
-            sum += __shfl_xor(sum, 32);
-            const float mu = sum * (1.0f / K);
-            float sq = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f);
-            const float sub = (LN == 2) ? mu : 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xv[s][j] = (xv[s][j] - sub) * rstd;
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[s][j] = (f16)xv[s][j];
-    } else {
-        const f16* src = (const f16*)xin + px * K + 8 * h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) b[s] = *(const half8*)(src + 16 * s);
     }
 
     const f16* wrow = W + (long)rowperm(r) * K + 8 * h;
-    f16* dst = y + px * y_stride + 8 * h;
     for (int nb = 0; nb < NB; ++nb) {
-        f32x16 acc;
+        f32x16 acc[PG];
         if (bias != nullptr) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[8 * u + j] = bias[32 * nb + 16 * u + 8 * h + j];
+                for (int j = 0; j < 8; ++j) {
+                    const float bv = bias[32 * nb + 16 * u + 8 * h + j];
+#pragma unroll
+                    for (int g = 0; g < PG; ++g) acc[g][8 * u + j] = bv;
+                }
         } else {
-            acc = zero16();
+#pragma unroll
+            for (int g = 0; g < PG; ++g) acc[g] = zero16();
         }
         const f16* wp = wrow + (long)nb * 32 * K;
+        const f16* wl = wp + (long)NB * 32 * K;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const half8 a = *(const half8*)(wp + 16 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc, 0, 0, 0);
-        }
+            const half8 al = *(const half8*)(wl + 16 * s);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n0 = 32 * nb + 16 * u + 8 * h;
-            if (valid && n0 + 8 <= n_store) {
-                half8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)acc[8 * u + j];
-                *(half8*)(dst + 32 * nb + 16 * u) = o;
+            for (int g = 0; g < PG; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g][s], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g][s], acc[g], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int g = 0; g < PG; ++g)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 32 * nb + 16 * u + 8 * h;
+                if (valid[g] && n0 + 8 <= n_store) {
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)acc[g][8 * u + j];
+                    *(half8*)(y + px[g] * y_stride + n0) = o;
+                }
+            }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pointwise (1x1) conv, "N-resident": fp32 accumulators for all N output channels of the wave's 32
-// pixels stay in registers; the wave streams over K (one or two concatenated sources).  fp32 out with
+// Pointwise (1x1) conv, "N-resident": fp32 accumulators for all N output channels of the wave's pixels
+// stay in registers; the wave streams over K (one or two concatenated sources).  fp32 out with
 // optional residual add.  Used for attention apply (per-tile matrix M on V) + residual, project_out
 // + residual (restormer_arch.py:92,131,148-149), reduce_chan on cat([up, skip]) (:260-261,265-266).
-template <int NB, bool IN_F32>
+template <int NB, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, int K0,
                                                  const void* __restrict__ x1, int K1,
                                                  const f16* __restrict__ W, long w_tile_stride,
@@ -151,71 +191,91 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
                                                  const float* resid, float* y,   // may alias (x += ...)
                                                  int N, int T, int P) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int chunks = (P + 31) >> 5;
+    const int chunks = (P + 32 * PG - 1) / (32 * PG);
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= (long)T * chunks) return;
     const int t = (int)(wv / chunks);
-    const int p = (int)(wv % chunks) * 32 + r;
-    const bool valid = p < P;
-    const long px = (long)t * P + (valid ? p : P - 1);
+    const int pbase = (int)(wv % chunks) * 32 * PG + r;
     const int K = K0 + K1;
+    bool valid[PG];
+    long px[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const int p = pbase + 32 * g;
+        valid[g] = p < P;
+        px[g] = (long)t * P + (valid[g] ? p : P - 1);
+    }
 
-    f32x16 acc[NB];
+    f32x16 acc[PG][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+        f32x16 init = zero16();
         if (bias != nullptr) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int n = 32 * nb + 16 * u + 8 * h + j;
-                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                    init[8 * u + j] = (n < N) ? bias[n] : 0.f;
                 }
-        } else {
-            acc[nb] = zero16();
         }
+#pragma unroll
+        for (int g = 0; g < PG; ++g) acc[g][nb] = init;
     }
 
+    // W: [2][NB*32][K] per matrix (hi plane, lo plane); w_tile_stride counts both planes
     const f16* wrow = W + (long)t * w_tile_stride + (long)rowperm(r) * K + 8 * h;
+    const long lo_off = (long)NB * 32 * K;
     const int KT = K >> 4;
     for (int s = 0; s < KT; ++s) {
         const int c0 = 16 * s;
-        half8 b;
-        if constexpr (IN_F32) {
-            const float* src = (c0 < K0) ? ((const float*)x0 + px * K0 + c0 + 8 * h)
-                                         : ((const float*)x1 + px * K1 + (c0 - K0) + 8 * h);
-            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
-        } else {
-            const f16* src = (c0 < K0) ? ((const f16*)x0 + px * K0 + c0 + 8 * h)
-                                       : ((const f16*)x1 + px * K1 + (c0 - K0) + 8 * h);
-            b = *(const half8*)src;
+        half8 b[PG];
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+            if constexpr (IN_F32) {
+                const float* src = (c0 < K0) ? ((const float*)x0 + px[g] * K0 + c0 + 8 * h)
+                                             : ((const float*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+                b[g] = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+            } else {
+                const f16* src = (c0 < K0) ? ((const f16*)x0 + px[g] * K0 + c0 + 8 * h)
+                                           : ((const f16*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+                b[g] = *(const half8*)src;
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const half8 a = *(const half8*)(wrow + (long)nb * 32 * K + c0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+            const half8 al = *(const half8*)(wrow + lo_off + (long)nb * 32 * K + c0);
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
+                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
+            }
         }
     }
 
-    if (!valid) return;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int g = 0; g < PG; ++g) {
+        if (!valid[g]) continue;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n0 = 32 * nb + 16 * u + 8 * h;
-            if (n0 + 8 <= N) {
-                f32x4 lo, hi;
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
-                if (resid != nullptr) {
-                    const f32x4 rl = *(const f32x4*)(resid + px * N + n0);
-                    const f32x4 rh = *(const f32x4*)(resid + px * N + n0 + 4);
-                    lo += rl; hi += rh;
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 32 * nb + 16 * u + 8 * h;
+                if (n0 + 8 <= N) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { lo[j] = acc[g][nb][8 * u + j]; hi[j] = acc[g][nb][8 * u + 4 + j]; }
+                    if (resid != nullptr) {
+                        const f32x4 rl = *(const f32x4*)(resid + px[g] * N + n0);
+                        const f32x4 rh = *(const f32x4*)(resid + px[g] * N + n0 + 4);
+                        lo += rl; hi += rh;
+                    }
+                    *(f32x4*)(y + px[g] * N + n0) = lo;
+                    *(f32x4*)(y + px[g] * N + n0 + 4) = hi;
                 }
-                *(f32x4*)(y + px * N + n0) = lo;
-                *(f32x4*)(y + px * N + n0 + 4) = hi;
             }
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,12 +285,12 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
 // MODE 0 (qkv, Cs = 3C): channel groups of q,k -> pixel-minor [T][H][WB][2C][8] (rows padded with
 //         zeros to WB*8 pixels so the Gram ignores them); v -> NHWC [T][H][W][C].
 // MODE 1 (GDFN gate, Cs = 2*Hp): out[T][H][W][Hp] = gelu(dw(in[.., :Hp])) * dw(in[.., Hp:]) (:90-91).
-template <int MODE>
+template <int PX>
 __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float* __restrict__ w,
                                          const float* __restrict__ bias, int H, int W, int Cs, int t,
-                                         int y, int x0, int ch0, float (&acc)[8][8]) {
+                                         int y, int x0, int ch0, float (&acc)[PX][8]) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < PX; ++p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
 #pragma unroll
@@ -238,9 +298,9 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
         const int yy = y + dy - 1;
         if (yy < 0 || yy >= H) continue;
         const f16* rowp = in + ((long)(t * H + yy) * W) * Cs + ch0;
-        half8 v[10];
+        half8 v[PX + 2];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < PX + 2; ++i) {
             const int xx = x0 - 1 + i;
             v[i] = (xx >= 0 && xx < W) ? *(const half8*)(rowp + (long)xx * Cs) : zero8();
         }
@@ -250,7 +310,7 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
             const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
             float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
+            for (int p = 0; p < PX; ++p)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[p + dx][e], wv[e], acc[p][e]);
         }
@@ -260,39 +320,43 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
         for (int e = 0; e < 8; ++e) {
             const float bv = bias[ch0 + e];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p][e] += bv;
+            for (int p = 0; p < PX; ++p) acc[p][e] += bv;
         }
     }
 }
 
+typedef f16 half4 __attribute__((ext_vector_type(4)));
+constexpr int DW_PX = 4;   // pixels per thread: 4 x 8 register block (8 x 8 ran at 1 wave/SIMD)
+
 __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, f16* __restrict__ qk,
                                                     f16* __restrict__ v, int T, int H, int W, int C) {
-    const int WB = (W + 7) >> 3, G = (3 * C) >> 3, GQK = (2 * C) >> 3;
-    const long total = (long)T * H * WB * G;
+    const int WB = (W + 7) >> 3, XB = 2 * WB, G = (3 * C) >> 3, GQK = (2 * C) >> 3;
+    const long total = (long)T * H * XB * G;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long rest = idx / G;
-    const int xb = (int)(rest % WB); rest /= WB;
+    const int xq = (int)(rest % XB); rest /= XB;     // 4-pixel block index along the (padded) row
     const int y = (int)(rest % H);
     const int t = (int)(rest / H);
-    const int x0 = xb * 8;
-    float acc[8][8];
-    dw_block<0>(in, w, bias, H, W, 3 * C, t, y, x0, g * 8, acc);
+    const int x0 = xq * DW_PX;
+    float acc[DW_PX][8];
+    dw_block<DW_PX>(in, w, bias, H, W, 3 * C, t, y, x0, g * 8, acc);
     if (g < GQK) {
-        f16* dst = qk + ((((long)(t * H + y) * WB + xb) * (2 * C)) + g * 8) * 8;
+        // pixel-minor [T][H][WB][2C][8]: this thread owns half (4 pixels) of each 8-pixel vector
+        f16* dst = qk + ((((long)(t * H + y) * WB + (xq >> 1)) * (2 * C)) + g * 8) * 8 + 4 * (xq & 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            half8 o;
+            half4 o;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) o[p] = (x0 + p < W) ? (f16)acc[p][e] : (f16)0.f;
-            *(half8*)(dst + e * 8) = o;
+            for (int p = 0; p < DW_PX; ++p) o[p] = (x0 + p < W) ? (f16)acc[p][e] : (f16)0.f;
+            *(half4*)(dst + e * 8) = o;
         }
     } else {
         f16* dst = v + ((long)(t * H + y) * W + x0) * C + (g - GQK) * 8;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < DW_PX; ++p) {
             if (x0 + p < W) {
                 half8 o;
 #pragma unroll
@@ -306,30 +370,26 @@ __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, 
 __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, f16* __restrict__ out,
                                                      int T, int H, int W, int Hp) {
-    const int WB = (W + 7) >> 3, G = Hp >> 3;
-    const long total = (long)T * H * WB * G;
+    const int XB = (W + DW_PX - 1) / DW_PX, G = Hp >> 3;
+    const long total = (long)T * H * XB * G;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long rest = idx / G;
-    const int xb = (int)(rest % WB); rest /= WB;
+    const int xq = (int)(rest % XB); rest /= XB;
     const int y = (int)(rest % H);
     const int t = (int)(rest / H);
-    const int x0 = xb * 8;
-    float a1[8][8], a2[8][8];
-    dw_block<1>(in, w, bias, H, W, 2 * Hp, t, y, x0, g * 8, a1);
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a1[p][e] = gelu_erf(a1[p][e]);
-    dw_block<1>(in, w, bias, H, W, 2 * Hp, t, y, x0, Hp + g * 8, a2);
+    const int x0 = xq * DW_PX;
+    float a1[DW_PX][8], a2[DW_PX][8];
+    dw_block<DW_PX>(in, w, bias, H, W, 2 * Hp, t, y, x0, g * 8, a1);
+    dw_block<DW_PX>(in, w, bias, H, W, 2 * Hp, t, y, x0, Hp + g * 8, a2);
     f16* dst = out + ((long)(t * H + y) * W + x0) * Hp + g * 8;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < DW_PX; ++p) {
         if (x0 + p < W) {
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(a1[p][e] * a2[p][e]);
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(gelu_erf(a1[p][e]) * a2[p][e]);
             *(half8*)(dst + (long)p * Hp) = o;
         }
     }
@@ -405,51 +465,92 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per (tile, head): reduce the S partial Grams in fixed order (bitwise reproducible), cosine-normalise
-// (F.normalize eps 1e-12), * temperature, softmax over the key channel (restormer_arch.py:121-125),
-// then fold project_out (:131):  M[o][hd*c + j] = sum_i Wo[o][hd*c + i] * attn[i][j]   so that
-// project_out(attn @ v) == conv1x1(v, M).  M: fp16 [T][NB*32][C], rows >= C are never touched (zeroed
-// once at allocation).
-__global__ __launch_bounds__(256) void k_attn_mix(const float* __restrict__ part, const float* __restrict__ wo,
-                                                  const float* __restrict__ temp, f16* __restrict__ M, int T,
-                                                  int C, int heads, int S, int NB) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// Attention matrix, two small kernels (restormer_arch.py:121-131 re-associated).
+// (1) k_attn_softmax, block = (tile, head, 8 q-rows): reduce the S partial Grams in fixed order (bitwise
+//     reproducible), cosine-normalise (F.normalize eps 1e-12, :121-122), * temperature (:124), softmax over
+//     the key channel (:125) -> attn fp32 [T][heads][c][c].
+// (2) k_attn_fold, block = (tile, head, 16 output rows): fold project_out (:131)
+//        M[o][hd*c + j] = sum_i Wo[o][hd*c + i] * attn[i][j]      so that project_out(attn @ v) == conv1x1(v, M)
+//     M: fp16 [T][2][NB*32][C] (hi plane, lo plane); rows >= C are never written (they only feed MFMA rows
+//     that are never stored).
+IRA_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+IRA_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ part, const float* __restrict__ temp,
+                                                      float* __restrict__ attn, int T, int C, int heads, int S) {
+    __shared__ float L[8 * 96];
+    __shared__ float nks[96];
+    __shared__ float nqs[8];
     const int c = C / heads;
     const int hd = blockIdx.x % heads, t = blockIdx.x / heads;
-    const int tid = threadIdx.x;
-    float* G = sm;                 // [c][c]
-    float* nq = sm + c * c;        // [c]
-    float* nk = nq + c;            // [c]
+    const int i0 = blockIdx.y * 8;
+    const int nrows = min(8, c - i0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rec = c * c + 2 * c;
-    for (int idx = tid; idx < rec; idx += blockDim.x) {
+    const float* pb = part + ((long)t * S * heads + hd) * rec;
+    const long sstride = (long)heads * rec;
+    for (int idx = tid; idx < nrows * c; idx += 256) {
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += part[(((long)t * S + s) * heads + hd) * rec + idx];
-        sm[idx] = a;
+        for (int s = 0; s < S; ++s) a += pb[s * sstride + (long)i0 * c + idx];
+        L[idx] = a;
+    }
+    for (int idx = tid; idx < c; idx += 256) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += pb[s * sstride + c * c + c + idx];
+        nks[idx] = a;
+    }
+    if (tid < nrows) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += pb[s * sstride + c * c + i0 + tid];
+        nqs[tid] = a;
     }
     __syncthreads();
     const float tmp = temp[hd];
-    for (int i = tid; i < c; i += blockDim.x) {
-        const float qn = fmaxf(sqrtf(nq[i]), 1e-12f);
-        float mx = -INFINITY;
-        for (int j = 0; j < c; ++j) {
-            const float kn = fmaxf(sqrtf(nk[j]), 1e-12f);
-            const float l = G[i * c + j] / (qn * kn) * tmp;
-            G[i * c + j] = l;
-            mx = fmaxf(mx, l);
-        }
-        float den = 0.f;
-        for (int j = 0; j < c; ++j) { const float e = expf(G[i * c + j] - mx); G[i * c + j] = e; den += e; }
-        const float inv = 1.0f / den;
-        for (int j = 0; j < c; ++j) G[i * c + j] *= inv;
+    for (int row = wave; row < nrows; row += 4) {
+        const float qn = fmaxf(sqrtf(nqs[row]), 1e-12f);
+        const int j0 = lane, j1 = lane + 64;
+        float l0 = -INFINITY, l1 = -INFINITY;
+        if (j0 < c) l0 = L[row * c + j0] / (qn * fmaxf(sqrtf(nks[j0]), 1e-12f)) * tmp;
+        if (j1 < c) l1 = L[row * c + j1] / (qn * fmaxf(sqrtf(nks[j1]), 1e-12f)) * tmp;
+        const float mx = wave_max(fmaxf(l0, l1));
+        const float e0 = (j0 < c) ? expf(l0 - mx) : 0.f;
+        const float e1 = (j1 < c) ? expf(l1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        float* dst = attn + (((long)t * heads + hd) * c + i0 + row) * c;
+        if (j0 < c) dst[j0] = e0 * inv;
+        if (j1 < c) dst[j1] = e1 * inv;
     }
+}
+
+__global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ attn, const float* __restrict__ wo,
+                                                   f16* __restrict__ M, int T, int C, int heads, int NB) {
+    extern __shared__ __attribute__((aligned(16))) float A[];   // [c][c]
+    const int c = C / heads;
+    const int hd = blockIdx.x % heads, t = blockIdx.x / heads;
+    const int o0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    const float* src = attn + ((long)t * heads + hd) * c * c;
+    for (int idx = tid; idx < c * c; idx += 256) A[idx] = src[idx];
     __syncthreads();
-    f16* Mt = M + (long)t * NB * 32 * C;
-    for (int idx = tid; idx < C * c; idx += blockDim.x) {
-        const int o = idx / c, j = idx % c;
+    f16* Mt = M + (long)t * 2 * NB * 32 * C;
+    f16* Ml = Mt + (long)NB * 32 * C;
+    for (int idx = tid; idx < 16 * c; idx += 256) {
+        const int o = o0 + idx / c, j = idx % c;
+        if (o >= C) continue;
         const float* wr = wo + (long)o * C + hd * c;
         float a = 0.f;
-        for (int i = 0; i < c; ++i) a = fmaf(wr[i], G[i * c + j], a);
-        Mt[(long)o * C + hd * c + j] = (f16)a;
+        for (int i = 0; i < c; ++i) a = fmaf(wr[i], A[i * c + j], a);
+        const f16 hi = (f16)a;
+        Mt[(long)o * C + hd * c + j] = hi;
+        Ml[(long)o * C + hd * c + j] = (f16)(a - (float)hi);
     }
 }
 
@@ -459,6 +560,8 @@ __global__ __launch_bounds__(256) void k_attn_mix(const float* __restrict__ part
 // (restormer_arch.py:171-189,243,281).   in fp32 NHWC [T][H][Wd][K]; W fp16 [9][NBtot*32][K]; out fp32.
 // MODE 0 plain [T][H][Wd][N]; 1 PixelUnshuffle(2) -> [T][H/2][Wd/2][4N]; 2 PixelShuffle(2) ->
 // [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281).
+// W: [2][9][NBtot*32][K] (hi, lo planes).  The fp32 input is split into fp16 hi + lo in registers as well
+// (three MFMAs per step: Wh.xh + Wl.xh + Wh.xl), so the conv sees ~fp32 operands at no extra traffic.
 template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, const float* __restrict__ skip,
@@ -493,19 +596,27 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     }
     const int KT = K >> 4;
     const f16* wbase = W + (long)rowperm(r) * K + 8 * h;
+    const long lo_off = 9L * NBtot * 32 * K;
     for (int tap = 0; tap < 9; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
         const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
         const f16* wt = wbase + (long)tap * NBtot * 32 * K;
         for (int s = 0; s < KT; ++s) {
-            half8 b = cvt8(*(const f32x4*)(src + 16 * s), *(const f32x4*)(src + 16 * s + 4));
-            if (!inb) b = zero8();
+            f32x4 lo4 = *(const f32x4*)(src + 16 * s), hi4 = *(const f32x4*)(src + 16 * s + 4);
+            if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
+            const half8 b = cvt8(lo4, hi4);
+            half8 bl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bl[j] = (f16)(lo4[j] - (float)b[j]); bl[4 + j] = (f16)(hi4[j] - (float)b[4 + j]); }
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 if (nb0 + nb < NBtot) {
                     const half8 a = *(const half8*)(wt + (long)(nb0 + nb) * 32 * K + 16 * s);
+                    const half8 al = *(const half8*)(wt + lo_off + (long)(nb0 + nb) * 32 * K + 16 * s);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
                 }
             }
         }
@@ -670,12 +781,17 @@ static inline unsigned grid1d(long total, int block, long cap = 1L << 30) {
     return (unsigned)g;
 }
 
-template <int KS>
-static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
-                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P) {
-    const long waves = (long)T * ((P + 31) / 32);
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+template <int KS, int PG>
+static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
+                                 f16* y, int ys, int ns, int NB, int T, int P) {
+    const long waves = (long)T * ((P + 32 * PG - 1) / (32 * PG));
     const dim3 grid(grid1d(waves, 4)), block(256);
-#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P)
+#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_, PG>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P)
     if (in_f32) {
         if (ln == 0) IRA_KRES(0, true); else if (ln == 1) IRA_KRES(1, true); else IRA_KRES(2, true);
     } else {
@@ -684,6 +800,17 @@ static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, i
     }
 #undef IRA_KRES
     return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
+                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P) {
+    static const int pg_env = env_int("IRA_KRES_PG", 0);
+    int pg = pg_env > 0 ? pg_env : (KS <= 4 ? 4 : (KS <= 12 ? 2 : 1));
+    while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;        // tiny tiles: do not pad a wave with empty groups
+    if constexpr (KS <= 6) { if (pg >= 4) return pw_kres_launch<KS, 4>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
+    if constexpr (KS <= 12) { if (pg >= 2) return pw_kres_launch<KS, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
+    return pw_kres_launch<KS, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P);
 }
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
@@ -698,15 +825,27 @@ hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mod
     }
 }
 
+template <int NB, int PG>
+static hipError_t pw_nres_launch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
+                                 const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
+                                 int T, int P) {
+    const long waves = (long)T * ((P + 32 * PG - 1) / (32 * PG));
+    const dim3 grid(grid1d(waves, 4)), block(256);
+    if (in_f32) hipLaunchKernelGGL((k_pw_nres<NB, true, PG>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    else hipLaunchKernelGGL((k_pw_nres<NB, false, PG>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    return hipGetLastError();
+}
+
 template <int NB>
 static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                    const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                    int T, int P) {
-    const long waves = (long)T * ((P + 31) / 32);
-    const dim3 grid(grid1d(waves, 4)), block(256);
-    if (in_f32) hipLaunchKernelGGL((k_pw_nres<NB, true>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    else hipLaunchKernelGGL((k_pw_nres<NB, false>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    return hipGetLastError();
+    static const int pg_env = env_int("IRA_NRES_PG", 0);
+    int pg = pg_env > 0 ? pg_env : (NB <= 4 ? 2 : 1);
+    while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;
+    if constexpr (NB <= 3) { if (pg >= 4) return pw_nres_launch<NB, 4>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
+    if constexpr (NB <= 6) { if (pg >= 2) return pw_nres_launch<NB, 2>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
+    return pw_nres_launch<NB, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P);
 }
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32, const void* W,
@@ -725,7 +864,7 @@ hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1
 hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias, void* qk, void* v,
                              int T, int H, int W, int C) {
     if (C % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)T * H * ((W + 7) / 8) * (3 * C / 8);
+    const long total = (long)T * H * (2 * ((W + 7) / 8)) * (3 * C / 8);
     hipLaunchKernelGGL(k_dwconv_qkv, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)qk,
                        (f16*)v, T, H, W, C);
     return hipGetLastError();
@@ -734,7 +873,7 @@ hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, con
 hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, const float* bias, void* out, int T,
                               int H, int W, int Hp) {
     if (Hp % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)T * H * ((W + 7) / 8) * (Hp / 8);
+    const long total = (long)T * H * ((W + DW_PX - 1) / DW_PX) * (Hp / 8);
     hipLaunchKernelGGL(k_dwconv_gate, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out,
                        T, H, W, Hp);
     return hipGetLastError();
@@ -755,11 +894,15 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
     return hipGetLastError();
 }
 
-hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, void* M, int T,
-                           int C, int heads, int S, int NB) {
+hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, float* attn_scratch,
+                           void* M, int T, int C, int heads, int S, int NB) {
     const int c = C / heads;
-    const size_t smem = (size_t)(c * c + 2 * c) * sizeof(float);
-    hipLaunchKernelGGL(k_attn_mix, dim3(T * heads), dim3(256), smem, st, part, wo, temp, (f16*)M, T, C, heads, S, NB);
+    if (c > 96) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_attn_softmax, dim3(T * heads, (c + 7) / 8), dim3(256), 0, st, part, temp, attn_scratch, T, C, heads, S);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_attn_fold, dim3(T * heads, (C + 15) / 16), dim3(256), (size_t)c * c * sizeof(float), st, attn_scratch, wo,
+                       (f16*)M, T, C, heads, NB);
     return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ struct ira_model {
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0;
     int ws_T = 0, ws_H = 0, ws_W = 0;
-    float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part;
+    float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
     void *qkvp, *qk, *v, *hp, *g, *M;
     int max_batch = 0;
     // harness scratch
@@ -155,18 +155,18 @@ bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, Bl
     const size_t NBq = up32(3 * C), NBc = up32(C);
     const bool cb = m->cfg.conv_bias != 0, lb = m->cfg.ln_with_bias != 0;
     m->err.clear();
-    b.qkv_w = wptr(m, p + ".qkv_w", true, NBq * C * 2);
+    b.qkv_w = wptr(m, p + ".qkv_w", true, 2 * NBq * C * 2);        // hi + lo planes
     b.qkv_b = (const float*)wptr(m, p + ".qkv_b", cb || lb, NBq * 4);
     b.dw1_w = (const float*)wptr(m, p + ".dw1_w", true, (size_t)9 * 3 * C * 4);
     b.dw1_b = (const float*)wptr(m, p + ".dw1_b", cb, (size_t)3 * C * 4);
     b.temp = (const float*)wptr(m, p + ".temp", true, (size_t)heads * 4);
     b.wo = (const float*)wptr(m, p + ".wo", true, (size_t)C * C * 4);
     b.wo_b = (const float*)wptr(m, p + ".wo_b", cb, NBc * 4);
-    b.pin_w = wptr(m, p + ".pin_w", true, (size_t)2 * Hp * C * 2);
+    b.pin_w = wptr(m, p + ".pin_w", true, (size_t)2 * 2 * Hp * C * 2);
     b.pin_b = (const float*)wptr(m, p + ".pin_b", cb || lb, (size_t)2 * Hp * 4);
     b.dw2_w = (const float*)wptr(m, p + ".dw2_w", true, (size_t)9 * 2 * Hp * 4);
     b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
-    b.pout_w = wptr(m, p + ".pout_w", true, NBc * Hp * 2);
+    b.pout_w = wptr(m, p + ".pout_w", true, 2 * NBc * Hp * 2);
     b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
     return m->err.empty();
 }
@@ -194,15 +194,15 @@ bool bind_weights(ira_model* m) {
     // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
     if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], m->dec1)) return false;
     if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], m->refine)) return false;
-    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)9 * up32(N) * K * 2); };
+    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
     m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
     m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
     m->down34 = c3("down3_4_w", g.C[2], g.C[2] / 2);
     m->up43 = c3("up4_3_w", g.C[3], g.C[3] * 2);
     m->up32 = c3("up3_2_w", g.C[2], g.C[2] * 2);
     m->up21 = c3("up2_1_w", g.C[1], g.C[1] * 2);
-    m->red3 = wptr(m, "reduce3_w", true, (size_t)up32(g.C[2]) * g.C[3] * 2);
-    m->red2 = wptr(m, "reduce2_w", true, (size_t)up32(g.C[1]) * g.C[2] * 2);
+    m->red3 = wptr(m, "reduce3_w", true, (size_t)2 * up32(g.C[2]) * g.C[3] * 2);
+    m->red2 = wptr(m, "reduce2_w", true, (size_t)2 * up32(g.C[1]) * g.C[2] * 2);
     m->red3_b = (const float*)wptr(m, "reduce3_b", cb, (size_t)up32(g.C[2]) * 4);
     m->red2_b = (const float*)wptr(m, "reduce2_b", cb, (size_t)up32(g.C[1]) * 4);
     m->out_w = c3("output_w", g.C[1], c.out_channels);
@@ -225,7 +225,7 @@ int ensure_workspace(ira_model* m, int T, int H, int W) {
            o_xd1 = take(t * g.P[0] * g.C[1] * 4), o_u3 = take(t * g.P[2] * g.C[2] * 4), o_u2 = take(t * g.P[1] * g.C[1] * 4),
            o_u1 = take(t * g.P[0] * g.C[0] * 4);
     // branch scratch: max over the (level, channel) pairs actually run; level-1 decoder runs at 2*dim
-    size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0;
+    size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0, mattn = 0;
     for (int l = 0; l < 4; ++l) {
         const int nvar = (l == 0) ? 2 : 1;
         for (int var = 0; var < nvar; ++var) {
@@ -240,11 +240,12 @@ int ensure_workspace(ira_model* m, int T, int H, int W) {
             mv = std::max(mv, t * g.P[l] * C * 2);
             mh = std::max(mh, t * g.P[l] * 2 * Hp * 2);
             mg = std::max(mg, t * g.P[l] * Hp * 2);
-            mM = std::max(mM, t * up32(C) * C * 2);
+            mM = std::max(mM, t * 2 * up32(C) * C * 2);
             mpart = std::max(mpart, t * S * heads * ((size_t)c * c + 2 * c) * 4);
+            mattn = std::max(mattn, t * (size_t)C * c * 4);
         }
     }
-    size_t o_q = take(mq), o_qk = take(mqk), o_v = take(mv), o_h = take(mh), o_g = take(mg), o_M = take(mM), o_p = take(mpart);
+    size_t o_q = take(mq), o_qk = take(mqk), o_v = take(mv), o_h = take(mh), o_g = take(mg), o_M = take(mM), o_p = take(mpart), o_a = take(mattn);
     hipError_t e = hipMalloc((void**)&m->ws, off);
     if (e != hipSuccess) {
         m->ws = nullptr; m->ws_T = 0;
@@ -256,7 +257,7 @@ int ensure_workspace(ira_model* m, int T, int H, int W) {
     m->xd3 = (float*)(b + o_xd3); m->xd2 = (float*)(b + o_xd2); m->xd1 = (float*)(b + o_xd1);
     m->u3 = (float*)(b + o_u3); m->u2 = (float*)(b + o_u2); m->u1 = (float*)(b + o_u1);
     m->qkvp = b + o_q; m->qk = b + o_qk; m->v = b + o_v; m->hp = b + o_h; m->g = b + o_g; m->M = b + o_M;
-    m->part = (float*)(b + o_p);
+    m->part = (float*)(b + o_p); m->attnA = (float*)(b + o_a);
     // M rows >= C are MFMA padding and must read as zero
     HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));
     return IRA_OK;
@@ -290,8 +291,8 @@ int run_block(ira_model* m, const Blk& b, float* x, int T, int H, int W, int C, 
     RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
     RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
     RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->M, T, C, heads, S, NBc));
-    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, (long)NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
+    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
+    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
     // GDFN (:88-93)
     RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
     RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
@@ -695,7 +696,15 @@ int ira_op_gram(ira_model_t* m, const void* qk, float* part, int T, int nblk, in
 
 int ira_op_attn_mix(ira_model_t* m, const float* part, const float* wo, const float* temp, void* M, int T, int C,
                     int heads, int S, int NB) {
-    OP_BODY(m, "op", ira::launch_attn_mix(m->st, part, wo, temp, M, T, C, heads, S, NB));
+    if (!m) return gfail(IRA_ERR_ARG, "ira_op_attn_mix: model is NULL");
+    if (heads <= 0 || C % heads != 0) return gfail(IRA_ERR_ARG, "ira_op_attn_mix: bad C/heads");
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        hipSetDevice(m->device);
+        int rc = ensure_scratch(m, al256((size_t)T * C * (C / heads) * 4));
+        if (rc != IRA_OK) return rc;
+    }
+    OP_BODY(m, "op", ira::launch_attn_mix(m->st, part, wo, temp, (float*)m->hs, M, T, C, heads, S, NB));
 }
 
 int ira_op_conv3x3(ira_model_t* m, const float* in, const void* W, const float* bias, const float* skip, float* out,

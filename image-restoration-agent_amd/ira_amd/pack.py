@@ -6,10 +6,10 @@ the HIP kernels consume them (csrc/ira_kernels.hip):
 
 * LayerNorm gain folded into the following 1x1 conv:  conv(LN(x)) = (W diag(g)) core(x) + W b_ln,
   where core(x) is x*rstd (BiasFree, restormer_arch.py:37-39) or (x-mu)*rstd (WithBias, :54-57).
-* 1x1 weights fp16 ``[rows padded to 32][K]`` (rows are MFMA A-operand rows).
+* 1x1 weights fp16 ``[2][rows padded to 32][K]``: hi and lo planes (``split16``), rows are MFMA A-operand rows.
 * GDFN hidden width padded to a multiple of 32 (127 -> 128, ...): x1 occupies channels [0, Hp), x2
   [Hp, 2Hp); padded rows/cols are zero so gelu(0)*0 = 0 flows through (restormer_arch.py:88-93).
-* depthwise 3x3 weights fp32 tap-major ``[9][channels]``; dense 3x3 fp16 ``[9][rows padded][K]``.
+* depthwise 3x3 weights fp32 tap-major ``[9][channels]``; dense 3x3 fp16 ``[2][9][rows padded][K]``.
 * attention project_out kept fp32 ``[C][C]``: it is folded with the per-tile softmax on the device.
 """
 from __future__ import annotations
@@ -33,6 +33,15 @@ def _np(t) -> np.ndarray:
     return t.detach().cpu().float().numpy()
 
 
+def split16(a: np.ndarray) -> np.ndarray:
+    """fp32/fp64 array -> stacked [hi, lo] fp16 planes with hi + lo ~= a to ~2^-22 relative.
+    Every weight that feeds an MFMA is stored like this; the kernels issue one MFMA per plane."""
+    a = np.asarray(a, dtype=np.float64)
+    hi = a.astype(np.float16)
+    lo = (a - hi.astype(np.float64)).astype(np.float16)
+    return np.stack([hi, lo])
+
+
 def _pad_rows(a: np.ndarray, rows: int) -> np.ndarray:
     out = np.zeros((rows,) + a.shape[1:], dtype=a.dtype)
     out[:a.shape[0]] = a
@@ -49,9 +58,9 @@ def _hidden_remap(a: np.ndarray, hid: int, hp: int) -> np.ndarray:
 
 def _conv3_pack(w: np.ndarray) -> np.ndarray:
     n, k = w.shape[:2]
-    out = np.zeros((9, up32(n), k), dtype=np.float16)
-    out[:, :n, :] = w.reshape(n, k, 9).transpose(2, 0, 1).astype(np.float16)
-    return out
+    out = np.zeros((9, up32(n), k), dtype=np.float64)
+    out[:, :n, :] = w.reshape(n, k, 9).transpose(2, 0, 1)
+    return split16(out)                                                     # [2][9][rows][K]
 
 
 def _dw_pack(w: np.ndarray) -> np.ndarray:
@@ -67,8 +76,8 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     wq = _np(sd[f'{p}.attn.qkv.weight'])[:, :, 0, 0].astype(np.float64)          # [3C][C]
     wi = _np(sd[f'{p}.ffn.project_in.weight'])[:, :, 0, 0].astype(np.float64)    # [2hid][C]
 
-    out[f'{name}.qkv_w'] = _pad_rows((wq * g1[None, :]).astype(np.float16), up32(3 * dim))
-    out[f'{name}.pin_w'] = _hidden_remap((wi * g2[None, :]).astype(np.float16), hid, hp)
+    out[f'{name}.qkv_w'] = split16(_pad_rows(wq * g1[None, :], up32(3 * dim)))
+    out[f'{name}.pin_w'] = split16(_hidden_remap(wi * g2[None, :], hid, hp))
     bq = np.zeros(3 * dim, np.float64)
     bi = np.zeros(2 * hid, np.float64)
     has_b = False
@@ -88,9 +97,9 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     out[f'{name}.dw2_w'] = _dw_pack(_hidden_remap(_np(sd[f'{p}.ffn.dwconv.weight']), hid, hp))
     out[f'{name}.temp'] = _np(sd[f'{p}.attn.temperature']).reshape(-1).astype(np.float32)
     out[f'{name}.wo'] = np.ascontiguousarray(_np(sd[f'{p}.attn.project_out.weight'])[:, :, 0, 0])
-    wout = np.zeros((up32(dim), hp), np.float16)
-    wout[:dim, :hid] = _np(sd[f'{p}.ffn.project_out.weight'])[:, :, 0, 0].astype(np.float16)
-    out[f'{name}.pout_w'] = wout
+    wout = np.zeros((up32(dim), hp), np.float64)
+    wout[:dim, :hid] = _np(sd[f'{p}.ffn.project_out.weight'])[:, :, 0, 0]
+    out[f'{name}.pout_w'] = split16(wout)
     if cfg.bias:
         out[f'{name}.dw1_b'] = _np(sd[f'{p}.attn.qkv_dwconv.bias']).astype(np.float32)
         out[f'{name}.dw2_b'] = _hidden_remap(_np(sd[f'{p}.ffn.dwconv.bias']).astype(np.float32), hid, hp)
@@ -124,7 +133,7 @@ def pack_arrays(sd, cfg: RestormerConfig) -> dict:
         out[dst] = _conv3_pack(_np(sd[src]))
     for src, dst in [('reduce_chan_level3', 'reduce3'), ('reduce_chan_level2', 'reduce2')]:
         w = _np(sd[f'{src}.weight'])[:, :, 0, 0]
-        out[f'{dst}_w'] = _pad_rows(w.astype(np.float16), up32(w.shape[0]))
+        out[f'{dst}_w'] = split16(_pad_rows(w, up32(w.shape[0])))
         if cfg.bias:
             out[f'{dst}_b'] = _pad_rows(_np(sd[f'{src}.bias']).astype(np.float32), up32(w.shape[0]))
     if cfg.bias:

@@ -41,6 +41,12 @@ class Contract:
         return r16(t) if self._on(tag) else t
 
 
+def GPU_CONTRACT():
+    """What csrc/ implements: fp32 residual stream, fp16 branch activations, weights as fp16 hi + lo
+    planes (~exact), dense 3x3 inputs split hi/lo in registers (~exact)."""
+    return Contract(res_fp16=False, act_fp16=True, off=['w', 'M', 'c3w', 'c3in'])
+
+
 def ln_core(x, ln_type):
     mu = x.mean(dim=1, keepdim=True)
     var = x.var(dim=1, keepdim=True, unbiased=False)
