@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Join rocprofv3 --kernel-trace and --pmc FETCH_SIZE / WRITE_SIZE passes of the same command
+(tools/prof_gpu.sh) into a per-kernel table: calls, average duration, HBM bytes per launch.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of a wide coalesced read, so reads = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE * 1024 is exact for 16-byte-per-lane stores.  Dispatches are matched across passes by
+(kernel name, grid size, ordinal), which is valid because the command is deterministic.
+
+usage: prof_summary.py <dir with prof_trace/ prof_fetch/ prof_write/> [out.md] [traffic.json]
+"""
+import csv
+import json
+import re
+import subprocess
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name
+    if n.startswith('_Z'):
+        try:
+            n = subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip() or n
+        except Exception:
+            pass
+    n = n.replace('ira::', '').replace('void ', '')
+    return n.split('(')[0]
+
+
+def load_trace(path):
+    rows = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            g = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+            rows[(short(r['Kernel_Name']), g)].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    return rows
+
+
+def load_pmc(path, counter):
+    rows = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] == counter:
+                rows[(short(r['Kernel_Name']), int(r['Grid_Size']))].append(float(r['Counter_Value']))
+    return rows
+
+
+def main():
+    d = sys.argv[1]
+    tr = load_trace(f'{d}/prof_trace/trace_kernel_trace.csv')
+    fe = load_pmc(f'{d}/prof_fetch/fetch_counter_collection.csv', 'FETCH_SIZE')
+    wr = load_pmc(f'{d}/prof_write/write_counter_collection.csv', 'WRITE_SIZE')
+    total = sum(sum(v) for v in tr.values())
+    out = []
+    out.append('| kernel | grid (threads) | calls | avg us | % time | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | HBM GB/s |')
+    out.append('|---|---|---|---|---|---|---|---|')
+    traffic = {}
+    for key, durs in sorted(tr.items(), key=lambda kv: -sum(kv[1])):
+        n = len(durs)
+        avg = sum(durs) / n
+        f = fe.get(key, [])
+        w = wr.get(key, [])
+        rd = 2.0 * 1024 * sum(f) / len(f) if f else float('nan')
+        wb = 1024.0 * sum(w) / len(w) if w else float('nan')
+        gbs = (rd + wb) / avg if f and w else float('nan')
+        out.append(f'| {key[0]} | {key[1]} | {n} | {avg / 1e3:.1f} | {100 * sum(durs) / total:.1f} | {rd / 1e6:.1f} | {wb / 1e6:.1f} | {gbs:.0f} |')
+        traffic[f'{key[0]}|grid{key[1]}'] = {'calls': n, 'avg_us': avg / 1e3, 'hbm_read_bytes': rd, 'hbm_write_bytes': wb}
+    text = f'total kernel time {total / 1e6:.2f} ms over {sum(len(v) for v in tr.values())} dispatches\n\n' + '\n'.join(out) + '\n'
+    if len(sys.argv) > 2:
+        open(sys.argv[2], 'w').write(text)
+    if len(sys.argv) > 3:
+        json.dump(traffic, open(sys.argv[3], 'w'), indent=1)
+    print(text)
+
+
+if __name__ == '__main__':
+    main()
