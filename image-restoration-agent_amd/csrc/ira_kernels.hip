@@ -17,7 +17,9 @@
 //   D[32 ch][32 px] += A[32 ch][16 k] * B[16 k][32 px]
 //   lane l: r = l & 31, h = l >> 5.
 //   B fragment of lane (r,h): 8 consecutive input channels 16s+8h .. +7 of pixel r   (one 16-byte load, NHWC)
-//   A fragment of lane (r,h): W[row 32nb + rowperm(r)][16s+8h .. +7]                 (one 16-byte load, [N][K])
+//   A fragment of lane (r,h): W[row 32nb + rowperm(r)][16s+8h .. +7].  Weights are stored FRAGMENT-MAJOR,
+//                             [plane][nb][s][lane][8], so one A load is one contiguous 1 KB per wave (a row-major
+//                             [N][K] matrix costs 32-64 cache lines per load instruction: TA-bound)
 //   D: lane (r,h), register t holds MFMA row (t&3) + 8(t>>2) + 4h.  With rowperm() below that row is
 //      output channel 32nb + 16(t>>3) + 8h + (t&7): each lane owns two runs of 8 consecutive
 //      channels of ITS pixel -> 16/32-byte NHWC stores, and the registers are already the B fragment
@@ -34,6 +36,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define IRA_DEV __device__ __forceinline__
+
+// XCD-aware work order (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin
+// over the 8 XCDs, each with its own L2.  Remap so that every XCD walks one CONTIGUOUS chunk of the
+// logical (tile, row, x) order: vertically adjacent patches then meet in the same L2 (the 3x3 halo
+// re-reads cost 3-6x HBM/fabric traffic without this, profiles/r01_v2_*).  Bijective for any block count.
+IRA_DEV long xcd_swizzle(long bid, long nblk) {
+    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+}
 
 IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
 
@@ -76,7 +87,6 @@ template <int KS, int LN, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, f16* __restrict__ y,
                                                  int y_stride, int n_store, int NB, int T, int P) {
-    // W: [2][NB*32][K]  (hi plane, lo plane)
     constexpr int K = KS * 16;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int chunks = (P + 32 * PG - 1) / (32 * PG);
@@ -135,7 +145,8 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
         }
     }
 
-    const f16* wrow = W + (long)rowperm(r) * K + 8 * h;
+    // W: fragment-major [2][NB][KS][64][8]
+    const f16* wrow = W + lane * 8;
     for (int nb = 0; nb < NB; ++nb) {
         f32x16 acc[PG];
         if (bias != nullptr) {
@@ -151,12 +162,12 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
 #pragma unroll
             for (int g = 0; g < PG; ++g) acc[g] = zero16();
         }
-        const f16* wp = wrow + (long)nb * 32 * K;
-        const f16* wl = wp + (long)NB * 32 * K;
+        const f16* wp = wrow + (long)nb * KS * 512;
+        const f16* wl = wp + (long)NB * KS * 512;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const half8 a = *(const half8*)(wp + 16 * s);
-            const half8 al = *(const half8*)(wl + 16 * s);
+            const half8 a = *(const half8*)(wp + s * 512);
+            const half8 al = *(const half8*)(wl + s * 512);
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g][s], acc[g], 0, 0, 0);
@@ -223,10 +234,10 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
         for (int g = 0; g < PG; ++g) acc[g][nb] = init;
     }
 
-    // W: [2][NB*32][K] per matrix (hi plane, lo plane); w_tile_stride counts both planes
-    const f16* wrow = W + (long)t * w_tile_stride + (long)rowperm(r) * K + 8 * h;
-    const long lo_off = (long)NB * 32 * K;
+    // W: fragment-major [2][NB][KT][64][8] per matrix (hi plane, lo plane); w_tile_stride counts both planes
     const int KT = K >> 4;
+    const f16* wrow = W + (long)t * w_tile_stride + lane * 8;
+    const long lo_off = (long)NB * KT * 512;
     for (int s = 0; s < KT; ++s) {
         const int c0 = 16 * s;
         half8 b[PG];
@@ -244,8 +255,8 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const half8 a = *(const half8*)(wrow + (long)nb * 32 * K + c0);
-            const half8 al = *(const half8*)(wrow + lo_off + (long)nb * 32 * K + c0);
+            const half8 a = *(const half8*)(wrow + ((long)nb * KT + s) * 512);
+            const half8 al = *(const half8*)(wrow + lo_off + ((long)nb * KT + s) * 512);
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
                 acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, 
                                                     f16* __restrict__ v, int T, int H, int W, int C) {
     const int WB = (W + 7) >> 3, XB = 2 * WB, G = (3 * C) >> 3, GQK = (2 * C) >> 3;
     const long total = (long)T * H * XB * G;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long rest = idx / G;
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
                                                      int T, int H, int W, int Hp) {
     const int XB = (W + DW_PX - 1) / DW_PX, G = Hp >> 3;
     const long total = (long)T * H * XB * G;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long rest = idx / G;
@@ -471,8 +482,8 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
 //     the key channel (:125) -> attn fp32 [T][heads][c][c].
 // (2) k_attn_fold, block = (tile, head, 16 output rows): fold project_out (:131)
 //        M[o][hd*c + j] = sum_i Wo[o][hd*c + i] * attn[i][j]      so that project_out(attn @ v) == conv1x1(v, M)
-//     M: fp16 [T][2][NB*32][C] (hi plane, lo plane); rows >= C are never written (they only feed MFMA rows
-//     that are never stored).
+//     M: fp16 fragment-major [T][2][NB][C/16][64][8] (hi plane, lo plane); rows >= C are never written (they
+//     only feed MFMA rows that are never stored).
 IRA_DEV float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -540,17 +551,22 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ att
     const float* src = attn + ((long)t * heads + hd) * c * c;
     for (int idx = tid; idx < c * c; idx += 256) A[idx] = src[idx];
     __syncthreads();
-    f16* Mt = M + (long)t * 2 * NB * 32 * C;
-    f16* Ml = Mt + (long)NB * 32 * C;
+    // M is written fragment-major [2][NB][C/16][64][8]: element (row o, col k) lives at
+    // nb = o/32, lane = 32*((k%16)/8) + rowperm(o%32) (rowperm is an involution), s = k/16, j = k%8
+    const int KT = C >> 4;
+    f16* Mt = M + (long)t * 2 * NB * KT * 512;
+    f16* Ml = Mt + (long)NB * KT * 512;
     for (int idx = tid; idx < 16 * c; idx += 256) {
         const int o = o0 + idx / c, j = idx % c;
         if (o >= C) continue;
         const float* wr = wo + (long)o * C + hd * c;
         float a = 0.f;
         for (int i = 0; i < c; ++i) a = fmaf(wr[i], A[i * c + j], a);
+        const int k = hd * c + j;
+        const long off = (((long)(o >> 5) * KT + (k >> 4)) * 64 + 32 * ((k >> 3) & 1) + rowperm(o & 31)) * 8 + (k & 7);
         const f16 hi = (f16)a;
-        Mt[(long)o * C + hd * c + j] = hi;
-        Ml[(long)o * C + hd * c + j] = (f16)(a - (float)hi);
+        Mt[off] = hi;
+        Ml[off] = (f16)(a - (float)hi);
     }
 }
 
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ att
 // (restormer_arch.py:171-189,243,281).   in fp32 NHWC [T][H][Wd][K]; W fp16 [9][NBtot*32][K]; out fp32.
 // MODE 0 plain [T][H][Wd][N]; 1 PixelUnshuffle(2) -> [T][H/2][Wd/2][4N]; 2 PixelShuffle(2) ->
 // [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281).
-// W: [2][9][NBtot*32][K] (hi, lo planes).  The fp32 input is split into fp16 hi + lo in registers as well
+// W: fragment-major [2][9][NBtot][K/16][64][8] (hi, lo planes).  The fp32 input is split into fp16 hi + lo in registers as well
 // (three MFMAs per step: Wh.xh + Wl.xh + Wh.xl), so the conv sees ~fp32 operands at no extra traffic.
 template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const f16* __restrict__ W,
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int P = H * Wd;
     const int chunks = (P + 31) >> 5;
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long wv = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (wv >= (long)T * chunks) return;
     const int nb0 = blockIdx.y * NBW;
     const int t = (int)(wv / chunks);
@@ -595,13 +611,13 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
         }
     }
     const int KT = K >> 4;
-    const f16* wbase = W + (long)rowperm(r) * K + 8 * h;
-    const long lo_off = 9L * NBtot * 32 * K;
+    const f16* wbase = W + lane * 8;                 // fragment-major [2][9][NBtot][KT][64][8]
+    const long lo_off = 9L * NBtot * KT * 512;
     for (int tap = 0; tap < 9; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
         const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
-        const f16* wt = wbase + (long)tap * NBtot * 32 * K;
+        const f16* wt = wbase + (long)tap * NBtot * KT * 512;
         for (int s = 0; s < KT; ++s) {
             f32x4 lo4 = *(const f32x4*)(src + 16 * s), hi4 = *(const f32x4*)(src + 16 * s + 4);
             if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
@@ -612,8 +628,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 if (nb0 + nb < NBtot) {
-                    const half8 a = *(const half8*)(wt + (long)(nb0 + nb) * 32 * K + 16 * s);
-                    const half8 al = *(const half8*)(wt + lo_off + (long)(nb0 + nb) * 32 * K + 16 * s);
+                    const half8 a = *(const half8*)(wt + ((long)(nb0 + nb) * KT + s) * 512);
+                    const half8 al = *(const half8*)(wt + lo_off + ((long)(nb0 + nb) * KT + s) * 512);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
@@ -652,6 +668,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, const float* __restrict__ w,
                                                const float* __restrict__ bias, float* __restrict__ out, int T,
                                                int H, int W, int ic, int C) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [9*ic][C]: (tap, ci) major, channel minor
+    for (int i = threadIdx.x; i < C * ic * 9; i += blockDim.x) {
+        const int o = i / (ic * 9), rem = i % (ic * 9), ci = rem / 9, tap = rem % 9;
+        wl[(tap * ic + ci) * C + o] = w[i];
+    }
+    __syncthreads();
     const int G = C >> 3;
     const long total = (long)T * H * W * G;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -673,9 +695,10 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, con
             const float* src = in + ((long)(t * H + yy) * W + xx) * ic;
             for (int ci = 0; ci < ic; ++ci) {
                 const float v = src[ci];
+                const float* wp = wl + ((ky * 3 + kx) * ic + ci) * C + g * 8;
+                const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    acc[e] = fmaf(v, w[((long)(g * 8 + e) * ic + ci) * 9 + ky * 3 + kx], acc[e]);
+                for (int e = 0; e < 4; ++e) { acc[e] = fmaf(v, w0[e], acc[e]); acc[4 + e] = fmaf(v, w1[e], acc[4 + e]); }
             }
         }
     }
@@ -941,7 +964,7 @@ hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const f
                         int W, int ic, int C) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)T * H * W * (C / 8);
-    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), 0, st, in, w, bias, out, T, H, W, ic, C);
+    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), (size_t)C * ic * 9 * sizeof(float), st, in, w, bias, out, T, H, W, ic, C);
     return hipGetLastError();
 }
 

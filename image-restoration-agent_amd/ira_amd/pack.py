@@ -6,10 +6,11 @@ the HIP kernels consume them (csrc/ira_kernels.hip):
 
 * LayerNorm gain folded into the following 1x1 conv:  conv(LN(x)) = (W diag(g)) core(x) + W b_ln,
   where core(x) is x*rstd (BiasFree, restormer_arch.py:37-39) or (x-mu)*rstd (WithBias, :54-57).
-* 1x1 weights fp16 ``[2][rows padded to 32][K]``: hi and lo planes (``split16``), rows are MFMA A-operand rows.
+* 1x1 weights fp16, hi and lo planes (``split16``), each in MFMA-fragment-major order
+  ``[NB][K/16][64 lanes][8]`` (``frag_major``): one A-operand load of a wave is one contiguous 1 KB.
 * GDFN hidden width padded to a multiple of 32 (127 -> 128, ...): x1 occupies channels [0, Hp), x2
   [Hp, 2Hp); padded rows/cols are zero so gelu(0)*0 = 0 flows through (restormer_arch.py:88-93).
-* depthwise 3x3 weights fp32 tap-major ``[9][channels]``; dense 3x3 fp16 ``[2][9][rows padded][K]``.
+* depthwise 3x3 weights fp32 tap-major ``[9][channels]``; dense 3x3 fp16 ``[2][9]`` x fragment-major.
 * attention project_out kept fp32 ``[C][C]``: it is folded with the per-tile softmax on the device.
 """
 from __future__ import annotations
@@ -42,6 +43,22 @@ def split16(a: np.ndarray) -> np.ndarray:
     return np.stack([hi, lo])
 
 
+ROWPERM = np.array([16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3) for i in range(32)])
+
+
+def frag_major(w: np.ndarray) -> np.ndarray:
+    """[..., rows (multiple of 32), K (multiple of 16)] -> [..., NB, K/16, 64, 8]: MFMA A-fragment order of
+    csrc/ira_kernels.hip.  Lane l = 32*h + r of fragment (nb, s) holds W[32nb + rowperm(r)][16s + 8h + j],
+    j = 0..7, so that one A load of a wave is one contiguous 1 KB."""
+    *lead, rows, k = w.shape
+    nb, ks = rows // 32, k // 16
+    a = w.reshape(*lead, nb, 32, ks, 2, 8)
+    a = np.take(a, ROWPERM, axis=len(lead) + 1)                       # [.., nb, r, s, h, j]
+    n = len(lead)
+    a = np.transpose(a, list(range(n)) + [n, n + 2, n + 3, n + 1, n + 4])   # [.., nb, s, h, r, j]
+    return np.ascontiguousarray(a.reshape(*lead, nb, ks, 64, 8))
+
+
 def _pad_rows(a: np.ndarray, rows: int) -> np.ndarray:
     out = np.zeros((rows,) + a.shape[1:], dtype=a.dtype)
     out[:a.shape[0]] = a
@@ -60,7 +77,7 @@ def _conv3_pack(w: np.ndarray) -> np.ndarray:
     n, k = w.shape[:2]
     out = np.zeros((9, up32(n), k), dtype=np.float64)
     out[:, :n, :] = w.reshape(n, k, 9).transpose(2, 0, 1)
-    return split16(out)                                                     # [2][9][rows][K]
+    return frag_major(split16(out))                                         # [2][9][NB][K/16][64][8]
 
 
 def _dw_pack(w: np.ndarray) -> np.ndarray:
@@ -76,8 +93,8 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     wq = _np(sd[f'{p}.attn.qkv.weight'])[:, :, 0, 0].astype(np.float64)          # [3C][C]
     wi = _np(sd[f'{p}.ffn.project_in.weight'])[:, :, 0, 0].astype(np.float64)    # [2hid][C]
 
-    out[f'{name}.qkv_w'] = split16(_pad_rows(wq * g1[None, :], up32(3 * dim)))
-    out[f'{name}.pin_w'] = split16(_hidden_remap(wi * g2[None, :], hid, hp))
+    out[f'{name}.qkv_w'] = frag_major(split16(_pad_rows(wq * g1[None, :], up32(3 * dim))))
+    out[f'{name}.pin_w'] = frag_major(split16(_hidden_remap(wi * g2[None, :], hid, hp)))
     bq = np.zeros(3 * dim, np.float64)
     bi = np.zeros(2 * hid, np.float64)
     has_b = False
@@ -99,7 +116,7 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     out[f'{name}.wo'] = np.ascontiguousarray(_np(sd[f'{p}.attn.project_out.weight'])[:, :, 0, 0])
     wout = np.zeros((up32(dim), hp), np.float64)
     wout[:dim, :hid] = _np(sd[f'{p}.ffn.project_out.weight'])[:, :, 0, 0]
-    out[f'{name}.pout_w'] = split16(wout)
+    out[f'{name}.pout_w'] = frag_major(split16(wout))
     if cfg.bias:
         out[f'{name}.dw1_b'] = _np(sd[f'{p}.attn.qkv_dwconv.bias']).astype(np.float32)
         out[f'{name}.dw2_b'] = _hidden_remap(_np(sd[f'{p}.ffn.dwconv.bias']).astype(np.float32), hid, hp)
@@ -133,7 +150,7 @@ def pack_arrays(sd, cfg: RestormerConfig) -> dict:
         out[dst] = _conv3_pack(_np(sd[src]))
     for src, dst in [('reduce_chan_level3', 'reduce3'), ('reduce_chan_level2', 'reduce2')]:
         w = _np(sd[f'{src}.weight'])[:, :, 0, 0]
-        out[f'{dst}_w'] = split16(_pad_rows(w, up32(w.shape[0])))
+        out[f'{dst}_w'] = frag_major(split16(_pad_rows(w, up32(w.shape[0]))))
         if cfg.bias:
             out[f'{dst}_b'] = _pad_rows(_np(sd[f'{src}.bias']).astype(np.float32), up32(w.shape[0]))
     if cfg.bias:

@@ -50,10 +50,10 @@ def up32(n):
 
 
 def split16(w):
-    """fp32 -> stacked [hi, lo] fp16 planes (ira_amd.pack.split16): hi + lo ~= w to ~2^-22."""
-    hi = w.half()
-    lo = (w.double() - hi.double()).half()
-    return torch.stack([hi, lo])
+    """fp32 [..., rows, K] -> device layout of ira_amd.pack: stacked [hi, lo] fp16 planes (hi + lo ~= w to
+    ~2^-22), each in MFMA-fragment-major order [..., NB, K/16, 64, 8]."""
+    from ira_amd.pack import frag_major, split16 as _s16
+    return torch.from_numpy(frag_major(_s16(w.double().numpy())))
 
 
 def close(a, b, rtol, atol_scale=1e-3):
@@ -134,7 +134,7 @@ def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
     y = dev(res.clone()) if resid else torch.full((T * P, N), float('nan')).cuda()
     x0d = dev(x0 if in_f32 else x0.half())
     x1d = dev(x1) if K1 else None
-    Wd = dev(split16(Wp).transpose(0, 1))            # [nW][2][rows][K]
+    Wd = dev(split16(Wp).transpose(0, 1))            # [nW][2][NB][K/16][64][8]
     bd = dev(bias) if with_bias else None
     rc = ctx._lib.ira_op_pw_nres(ctx.handle, ptr(x0d), K0, ptr(x1d), K1, int(in_f32), ptr(Wd),
                                  2 * NB * 32 * K if per_tile else 0, ptr(bd), ptr(y) if resid else None, ptr(y),
@@ -143,6 +143,18 @@ def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
     # hi + lo weight planes: the result must be at fp32-accumulation accuracy, far below one fp16 ulp of W
     # (2.4e-4 relative).  This also proves the lo plane (often fp16-subnormal) is not flushed by the MFMA.
     close(y.cpu(), ref, 2e-5, 2e-5)
+
+
+def unfrag(m):
+    """inverse of frag_major: [..., NB, KS, 64, 8] -> [..., NB*32, KS*16]."""
+    from ira_amd.pack import ROWPERM
+    *lead, nb, ks, _, _ = m.shape
+    a = m.reshape(*lead, nb, ks, 2, 32, 8)                  # [.., nb, s, h, r, j]
+    n = len(lead)
+    a = a.permute(*range(n), n, n + 3, n + 1, n + 2, n + 4)  # [.., nb, r, s, h, j]
+    out = torch.empty_like(a)
+    out[..., torch.from_numpy(ROWPERM), :, :, :] = a        # row rowperm(r) <- lane r
+    return out.reshape(*lead, nb * 32, ks * 16)
 
 
 def px_minor(t_nchw):
@@ -229,11 +241,11 @@ def test_attn_mix(ctx, C, heads, T, S):
     attn = (logits * temp.view(1, heads, 1, 1)).softmax(-1)
     ref = torch.einsum('ohi,thij->tohj', wo.view(C, heads, c), attn).reshape(T, C, C)
     NB = up32(C) // 32
-    M = torch.zeros(T, 2, NB * 32, C, dtype=torch.float16).cuda()
+    M = torch.zeros(T, 2, NB, C // 16, 64, 8, dtype=torch.float16).cuda()
     pd, wod, td = dev(part), dev(wo), dev(temp)     # keep the device tensors alive across the call
     rc = ctx._lib.ira_op_attn_mix(ctx.handle, ptr(pd), ptr(wod), ptr(td), ptr(M), T, C, heads, S, NB)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
-    Mc = M.cpu().float()
+    Mc = unfrag(M.cpu().float())                         # [T][2][NB*32][C]
     close(Mc[:, 0, :C], ref, 2e-3)                       # hi plane alone: fp16 accuracy
     close(Mc[:, 0, :C] + Mc[:, 1, :C], ref, 2e-5, 2e-5)  # hi + lo: fp32 accuracy
 
