@@ -28,6 +28,12 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
                            float* attn_scratch, void* M, int T, int C, int heads, int S, int NB);
 
+// Fused GDFN (ira_ffn_fused.hip): x_out = x + ffn(LN(x)); x_out must not alias x.  Supported for C in {48, 96}.
+bool ffn_fused_supported(int C, int Hp);
+hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln_mode, int C, const void* Win,
+                            const float* bin, const float* dww, const float* dwb, const void* Wout, const float* bout,
+                            int T, int H, int W, int Hp);
+
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);
 

@@ -55,6 +55,8 @@ struct ira_model {
     char* ws = nullptr; size_t ws_bytes = 0;
     int ws_T = 0, ws_H = 0, ws_W = 0;
     float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
+    float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
+    bool use_fused_ffn = true;
     void *qkvp, *qk, *v, *hp, *g, *M;
     int max_batch = 0;
     // harness scratch
@@ -224,6 +226,8 @@ int ensure_workspace(ira_model* m, int T, int H, int W) {
            o_x4 = take(t * g.P[3] * g.C[3] * 4), o_xd3 = take(t * g.P[2] * g.C[2] * 4), o_xd2 = take(t * g.P[1] * g.C[1] * 4),
            o_xd1 = take(t * g.P[0] * g.C[1] * 4), o_u3 = take(t * g.P[2] * g.C[2] * 4), o_u2 = take(t * g.P[1] * g.C[1] * 4),
            o_u1 = take(t * g.P[0] * g.C[0] * 4);
+    size_t o_ae1 = take(t * g.P[0] * g.C[0] * 4), o_ad1 = take(t * g.P[0] * g.C[1] * 4), o_ae2 = take(t * g.P[1] * g.C[1] * 4),
+           o_ad2 = take(t * g.P[1] * g.C[1] * 4);
     // branch scratch: max over the (level, channel) pairs actually run; level-1 decoder runs at 2*dim
     size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0, mattn = 0;
     for (int l = 0; l < 4; ++l) {
@@ -256,6 +260,7 @@ int ensure_workspace(ira_model* m, int T, int H, int W) {
     m->xe1 = (float*)(b + o_xe1); m->xe2 = (float*)(b + o_xe2); m->xe3 = (float*)(b + o_xe3); m->x4 = (float*)(b + o_x4);
     m->xd3 = (float*)(b + o_xd3); m->xd2 = (float*)(b + o_xd2); m->xd1 = (float*)(b + o_xd1);
     m->u3 = (float*)(b + o_u3); m->u2 = (float*)(b + o_u2); m->u1 = (float*)(b + o_u1);
+    m->ae1 = (float*)(b + o_ae1); m->ad1 = (float*)(b + o_ad1); m->ae2 = (float*)(b + o_ae2); m->ad2 = (float*)(b + o_ad2);
     m->qkvp = b + o_q; m->qk = b + o_qk; m->v = b + o_v; m->hp = b + o_h; m->g = b + o_g; m->M = b + o_M;
     m->part = (float*)(b + o_p); m->attnA = (float*)(b + o_a);
     // M rows >= C are MFMA padding and must read as zero
@@ -273,7 +278,9 @@ int ensure_scratch(ira_model* m, size_t bytes) {
 }
 
 // ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
-int run_block(ira_model* m, const Blk& b, float* x, int T, int H, int W, int C, int heads, int Hp) {
+// x: current residual stream buffer; alt: a second buffer of the same size (or nullptr).  The fused FFN writes
+// x -> alt and the two are swapped, so on return x still names the buffer holding the block's output.
+int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp) {
     const int P = H * W;
     char k_[8][64];
     if (m->profile) {
@@ -294,15 +301,22 @@ int run_block(ira_model* m, const Blk& b, float* x, int T, int H, int W, int C, 
     RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
     RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
     // GDFN (:88-93)
+    if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
+        char kf[64];
+        if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
+        RUN(m, kf, ira::launch_ffn_fused(st, x, alt, ln, C, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, T, H, W, Hp));
+        std::swap(x, alt);
+        return IRA_OK;
+    }
     RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
     RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
     RUN(m, k_[7], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
     return IRA_OK;
 }
 
-int run_stage(ira_model* m, const std::vector<Blk>& blks, float* x, int T, int H, int W, int C, int heads, int Hp) {
+int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp) {
     for (const Blk& b : blks) {
-        int rc = run_block(m, b, x, T, H, W, C, heads, Hp);
+        int rc = run_block(m, b, x, alt, T, H, W, C, heads, Hp);
         if (rc != IRA_OK) return rc;
     }
     return IRA_OK;
@@ -319,26 +333,29 @@ int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* o
     hipStream_t st = m->st;
     auto nb = [](int N) { return up32(N) / 32; };
 
-    RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, m->xe1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
-    if ((rc = run_stage(m, m->enc1, m->xe1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                              // :248
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe1, m->down12, nullptr, nullptr, m->xe2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
-    if ((rc = run_stage(m, m->enc2, m->xe2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe2, m->down23, nullptr, nullptr, m->xe3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
-    if ((rc = run_stage(m, m->enc3, m->xe3, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, m->xe3, m->down34, nullptr, nullptr, m->x4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
-    if ((rc = run_stage(m, m->lat, m->x4, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                                // :257
+    float *e1 = m->xe1, *e2 = m->xe2, *e3 = m->xe3, *l4 = m->x4, *d3 = m->xd3, *d2 = m->xd2, *d1 = m->xd1;
+    RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, e1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
+    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                         // :248
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
+    if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e2, m->down23, nullptr, nullptr, e3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
+    if ((rc = run_stage(m, m->enc3, e3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e3, m->down34, nullptr, nullptr, l4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
+    if ((rc = run_stage(m, m->lat, l4, nullptr, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                         // :257
 
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->x4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
-    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], m->xe3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, m->xd3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
-    if ((rc = run_stage(m, m->dec3, m->xd3, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->xd3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
-    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], m->xe2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, m->xd2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
-    if ((rc = run_stage(m, m->dec2, m->xd2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, m->xd2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
-    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], m->xe1, g.C[0], m->xd1, (long)T * g.P[0]));                                  // :270
-    if ((rc = run_stage(m, m->dec1, m->xd1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
-    if ((rc = run_stage(m, m->refine, m->xd1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
-    RUN(m, "conv3x3_out", ira::launch_conv3x3(st, m->xd1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, l4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], e3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, d3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
+    if ((rc = run_stage(m, m->dec3, d3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], e2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, d2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
+    if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
+    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], e1, g.C[0], d1, (long)T * g.P[0]));                                        // :270
+    float* a1 = m->ad1;
+    if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
+    a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
+    if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
+    RUN(m, "conv3x3_out", ira::launch_conv3x3(st, d1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
     return IRA_OK;
 }
 
@@ -710,6 +727,17 @@ int ira_op_attn_mix(ira_model_t* m, const float* part, const float* wo, const fl
 int ira_op_conv3x3(ira_model_t* m, const float* in, const void* W, const float* bias, const float* skip, float* out,
                    int mode, int T, int H, int Wd, int K, int N, int NB) {
     OP_BODY(m, "op", ira::launch_conv3x3(m->st, in, W, bias, skip, out, mode, T, H, Wd, K, N, NB));
+}
+
+int ira_op_ffn_fused(ira_model_t* m, const float* x, float* xo, int ln_mode, int C, const void* Win, const float* bin,
+                     const float* dww, const float* dwb, const void* Wout, const float* bout, int T, int H, int W, int Hp) {
+    OP_BODY(m, "op", ira::launch_ffn_fused(m->st, x, xo, ln_mode, C, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp));
+}
+
+int ira_set_fused_ffn(ira_model_t* m, int on) {
+    ENTER(m);
+    m->use_fused_ffn = on != 0;
+    return IRA_OK;
 }
 
 int ira_op_embed(ira_model_t* m, const float* in, const float* w, const float* bias, float* out, int T, int H, int W,

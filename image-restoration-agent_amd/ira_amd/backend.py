@@ -127,6 +127,9 @@ class RestormerBackend:
     def set_max_batch(self, n: int):
         self._ck(self._lib.ira_set_max_batch(self._h, int(n)), 'ira_set_max_batch')
 
+    def set_fused_ffn(self, on: bool):
+        self._ck(self._lib.ira_set_fused_ffn(self._h, 1 if on else 0), 'ira_set_fused_ffn')
+
     def sync(self):
         self._ck(self._lib.ira_sync(self._h), 'ira_sync')
 

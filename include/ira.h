@@ -178,6 +178,17 @@ int ira_op_attn_mix(ira_model_t* m, const float* part_dev, const float* wo_dev, 
 int ira_op_conv3x3(ira_model_t* m, const float* in_dev, const void* W_f16_dev, const float* bias_dev,
                    const float* skip_dev, float* out_dev, int mode, int T, int H, int W, int K, int N, int NB);
 
+/* Fused GDFN block, x_out = x + ffn(LN(x)) (restormer_arch.py:88-93,149) in one kernel; C in {48, 96}.
+ * x, x_out fp32 NHWC (T,H,W,C), must not alias.  Win: packed project_in (LN gain folded, hi/lo planes,
+ * fragment-major, hidden padded to Hp), bin fp32 [2*Hp] or NULL; dww fp32 [9][2*Hp], dwb [2*Hp] or NULL;
+ * Wout packed project_out, bout fp32 or NULL.  ln_mode 1 = BiasFree, 2 = WithBias. */
+int ira_op_ffn_fused(ira_model_t* m, const float* x_dev, float* x_out_dev, int ln_mode, int C,
+                     const void* Win_dev, const float* bin_dev, const float* dww_dev, const float* dwb_dev,
+                     const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
+
+/* Switch the fused GDFN kernel on (default) or off (three-kernel path); for A/B measurements. */
+int ira_set_fused_ffn(ira_model_t* m, int on);
+
 /* patch_embed (restormer_arch.py:156-165): fp32 NHWC (T,H,W,ic) -> fp32 (T,H,W,C), W fp32 [C][ic][3][3]. */
 int ira_op_embed(ira_model_t* m, const float* in_dev, const float* w_dev, const float* bias_dev,
                  float* out_dev, int T, int H, int W, int ic, int C);

@@ -312,3 +312,55 @@ def test_concat2(ctx):
     rc = ctx._lib.ira_op_concat2(ctx.handle, ptr(ad), 48, ptr(bd), 16, ptr(out), 37)
     assert rc == 0
     assert torch.equal(out.cpu(), torch.cat([a, b], 1))     # restormer_arch.py:270
+
+
+@pytest.mark.parametrize('C,hid,ln,T,H,W,bias', [
+    (48, 127, 1, 2, 11, 40, False),     # level-1 encoder block, ragged patch edges (H % 8, W % 32 != 0)
+    (96, 255, 1, 1, 16, 64, False),     # decoder level 1 / refinement / level 2
+    (96, 255, 2, 2, 9, 33, True),       # WithBias LN + conv biases
+    (48, 127, 2, 1, 8, 32, False),
+])
+def test_ffn_fused(ctx, C, hid, ln, T, H, W, bias):
+    """Whole GDFN block + residual in one kernel (restormer_arch.py:88-93,149) against the fp32 torch ops."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    g = torch.Generator().manual_seed(C + hid + ln)
+    Hp = up32(hid)
+    x = torch.randn(T, C, H, W, generator=g) * 1.5
+    sd = {
+        'b.norm1.body.weight': torch.ones(C), 'b.norm2.body.weight': 1 + 0.1 * torch.randn(C, generator=g),
+        'b.attn.temperature': torch.ones(1, 1, 1), 'b.attn.qkv.weight': torch.zeros(3 * C, C, 1, 1),
+        'b.attn.qkv_dwconv.weight': torch.zeros(3 * C, 1, 3, 3), 'b.attn.project_out.weight': torch.zeros(C, C, 1, 1),
+        'b.ffn.project_in.weight': torch.randn(2 * hid, C, 1, 1, generator=g) / C ** 0.5,
+        'b.ffn.dwconv.weight': torch.randn(2 * hid, 1, 3, 3, generator=g) / 3,
+        'b.ffn.project_out.weight': torch.randn(C, hid, 1, 1, generator=g) / hid ** 0.5,
+    }
+    if ln == 2:
+        sd['b.norm1.body.bias'] = torch.zeros(C)
+        sd['b.norm2.body.bias'] = 0.1 * torch.randn(C, generator=g)
+    if bias:
+        for k, n in [('attn.qkv', 3 * C), ('attn.qkv_dwconv', 3 * C), ('attn.project_out', C), ('ffn.project_in', 2 * hid),
+                     ('ffn.dwconv', 2 * hid), ('ffn.project_out', C)]:
+            sd[f'b.{k}.bias'] = 0.1 * torch.randn(n, generator=g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree' if ln == 1 else 'WithBias', bias=bias)
+    cfg.hidden = lambda d: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    # reference
+    from oracle import restormer_oracle as O
+    ln_type = 'BiasFree' if ln == 1 else 'WithBias'
+    xn = O.layer_norm(x, sd['b.norm2.body.weight'], sd.get('b.norm2.body.bias'), ln_type)
+    ref = (x + O.feed_forward(xn, sd, 'b.ffn')).permute(0, 2, 3, 1).contiguous()
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v))) for k, v in arrs.items()}
+    xd = dev(x.permute(0, 2, 3, 1))
+    out = torch.full(ref.shape, float('nan')).cuda()
+    rc = ctx._lib.ira_op_ffn_fused(ctx.handle, ptr(xd), ptr(out), ln, C, ptr(d['b.pin_w']), ptr(d.get('b.pin_b')),
+                                   ptr(d['b.dw2_w']), ptr(d.get('b.dw2_b')), ptr(d['b.pout_w']), ptr(d.get('b.pout_b')),
+                                   T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    # fp16 LN output / hidden / gated values inside: a few 1e-3 relative to the branch magnitude
+    err = (got - ref).abs().max().item()
+    scale = (ref - x.permute(0, 2, 3, 1)).abs().max().item()
+    assert err <= 4e-3 * scale + 1e-4, (err, scale)
