@@ -1,0 +1,285 @@
+"""Agent-facing tool / registry API, source-compatible with the reference's
+
+    AgenticIR/executor/tool.py:8-90            class Tool
+    AgenticIR/executor/multitask_tools.py:136-173   class Restormer(Tool)
+    AgenticIR/executor/__init__.py:24-169      class Executor, singleton ``executor``
+
+with the one difference that matters: ``Restormer._invoke`` runs the in-process HIP backend instead of
+``subprocess.run("conda run -n restormer python demo.py ...")`` (tool.py:64-70), so there is no process
+start, no torch import and no weight reload per call (SURVEY section 1, L2 -> L1 boundary).
+
+Contract kept (tool.py:33-62): ``tool(input_dir, output_dir, silent=False)``; ``input_dir`` holds exactly
+one image; ``output_dir`` is empty before and holds exactly ``output.png`` after; failures are Python
+exceptions (the agent catches and prints them, agentic_api.py:191-198).  Attributes read by the agent:
+``tool_name`` and ``subtask`` (utils/util.py:337-338, agentic_api.py:189,202).
+"""
+from __future__ import annotations
+
+import os
+import time
+from pathlib import Path
+from typing import Callable, Optional
+
+import numpy as np
+
+from .config import SUBTASK_TO_TASK, TASK_WEIGHT_FILE, canonical_subtask, task_config
+
+
+class Tool:
+    """Abstract tool (tool.py:8-31): same constructor arguments and attributes as the reference."""
+
+    def __init__(self, tool_name: str, subtask: str, work_dir: Optional[Path] = None,
+                 script_rel_path: Optional[Path | str] = None):
+        self.tool_name: str = tool_name
+        self.subtask: str = subtask
+        self.work_dir: Optional[Path] = None
+        self.script_path: Optional[Path] = None
+        if work_dir is not None:
+            assert script_rel_path is not None, "If `work_dir` is provided, `script_rel_path` should also be provided."
+            self.work_dir = Path().resolve() / 'executor' / subtask / 'tools' / work_dir
+            self.script_path = self.work_dir / script_rel_path
+
+    def __call__(self, input_dir: Path, output_dir: Path, silent: bool = False, *args) -> None:
+        """tool.py:33-49, print-for-print."""
+        input_dir, output_dir = Path(input_dir), Path(output_dir)
+        if not silent:
+            print('-' * 100)
+            print(f"Subtask\t: {self.subtask}")
+            print(f"Tool\t: {self.tool_name}")
+            print(f"Input\t: {list(input_dir.glob('*'))[0]}")
+        start_time = time.time()
+        self.input_dir = input_dir
+        self.output_dir = output_dir
+        self._precheck()
+        self._invoke(*args)
+        self._postcheck()
+        end_time = time.time()
+        if not silent:
+            print(f"Output\t: {list(output_dir.glob('*'))[0]}")
+            print(f"Time\t: {round(end_time - start_time, 3)}s")
+
+    def _precheck(self) -> None:
+        """tool.py:51-54."""
+        assert len(os.listdir(self.input_dir)) == 1, "The input directory should contain the input only."
+        assert os.listdir(self.output_dir) == [], "The output directory should be empty."
+
+    def _postcheck(self) -> None:
+        """tool.py:56-62: exactly one output, renamed to ``output.png`` if needed."""
+        output = list(self.output_dir.glob('*'))
+        assert len(output) == 1, "There're other files in the same directory as the output image."
+        if output[0].name != 'output.png':
+            output[0].replace(self.output_dir / 'output.png')
+
+    def _invoke(self, *args) -> None:
+        raise NotImplementedError("only in-process HIP tools are provided by ira_amd (tool.py:64-70 runs a subprocess)")
+
+    def _preprocess(self):
+        pass
+
+    def _postprocess(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+# weights: where a ``.pth`` comes from.  The reference reads
+#   <work_dir>/<Task dir>/pretrained_models/<file>.pth            (demo.py:52-69)
+#   <root>/<weight_dir>/<file>.pth                                (model_serving.py:52-53,77-94)
+# Neither exists offline, so the loader is injectable; the default looks under $IRA_RESTORMER_WEIGHTS.
+
+_TASK_DIR = {   # demo.py:53-66
+    'Motion_Deblurring': 'Motion_Deblurring', 'Single_Image_Defocus_Deblurring': 'Defocus_Deblurring',
+    'Deraining': 'Deraining', 'Real_Denoising': 'Denoising', 'Gaussian_Color_Denoising': 'Denoising',
+    'Gaussian_Gray_Denoising': 'Denoising',
+}
+
+
+def default_state_dict_loader(task: str, weight_dir: Optional[str] = None):
+    """``torch.load(weights)['params']`` (demo.py:101-102).  PyTorch is used for nothing else."""
+    root = weight_dir or os.environ.get('IRA_RESTORMER_WEIGHTS', '')
+    fname = TASK_WEIGHT_FILE[task]
+    candidates = [os.path.join(root, fname), os.path.join(root, _TASK_DIR[task], 'pretrained_models', fname)]
+    for path in candidates:
+        if root and os.path.isfile(path):
+            import torch
+            ckpt = torch.load(path, map_location='cpu')
+            return ckpt['params'] if 'params' in ckpt else ckpt
+    raise FileNotFoundError(f"Restormer weights for task {task!r} not found (looked for {candidates}); set "
+                            "IRA_RESTORMER_WEIGHTS or pass weight_dir / state_dict_loader")
+
+
+def seeded_state_dict_loader(seed: int = 0) -> Callable:
+    """Loader used by tests / benchmarks: the build's deterministic weights (no checkpoint offline)."""
+    def load(task: str, weight_dir=None):
+        from .weights import seeded_state_dict
+        return seeded_state_dict(task_config(task), seed)
+    return load
+
+
+class BackendCache:
+    """task -> RestormerBackend on one device; plays the role of RestormerService.models
+    (model_serving.py:57,101-105: 'model has been loaded, use cache')."""
+
+    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
+                 backend_factory: Optional[Callable] = None):
+        self.device = device
+        self.loader = state_dict_loader or default_state_dict_loader
+        self.weight_dir = weight_dir
+        self.factory = backend_factory
+        self.models: dict = {}
+
+    def get(self, task: str):
+        if task not in self.models:
+            cfg = task_config(task)
+            sd = self.loader(task, self.weight_dir)
+            if self.factory is not None:
+                self.models[task] = self.factory(cfg, sd, self.device)
+            else:
+                from .backend import RestormerBackend
+                self.models[task] = RestormerBackend(cfg, sd, device=self.device)
+        return self.models[task]
+
+    def close(self):
+        for be in self.models.values():
+            if hasattr(be, 'close'):
+                be.close()
+        self.models.clear()
+
+
+_default_cache: Optional[BackendCache] = None
+
+
+def default_cache() -> BackendCache:
+    global _default_cache
+    if _default_cache is None:
+        _default_cache = BackendCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+    return _default_cache
+
+
+def set_default_cache(cache: Optional[BackendCache]):
+    global _default_cache
+    _default_cache = cache
+
+
+# ------------------------------------------------------------------------------------------------
+def read_image(path, gray: bool = False) -> np.ndarray:
+    """demo.py:40-47 (cv2.imread + BGR2RGB / IMREAD_GRAYSCALE) with PIL: uint8 (h,w,3) RGB or (h,w,1)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if gray:
+            return np.asarray(im.convert('L'), dtype=np.uint8)[:, :, None].copy()
+        return np.asarray(im.convert('RGB'), dtype=np.uint8).copy()
+
+
+def write_png(path, img: np.ndarray):
+    """demo.py:43-50 (cv2.imwrite PNG): lossless, so the decoder/encoder library does not matter."""
+    from PIL import Image
+    a = np.asarray(img)
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    Image.fromarray(a).save(path, format='PNG')
+
+
+class Restormer(Tool):
+    """Restormer tool for denoising, motion deblurring, defocus deblurring and deraining
+    (multitask_tools.py:136-173), running on the MI355X backend in-process.
+
+    Like the reference tool it passes no ``--tile`` (multitask_tools.py:159-165): whole-image mode
+    (demo.py:129-131).  ``tile`` / ``tile_overlap`` can be set for the tiled mode of demo.py:132-153.
+    """
+
+    def __init__(self, subtask: str, cache: Optional[BackendCache] = None, tile: Optional[int] = None,
+                 tile_overlap: int = 32):
+        super().__init__(tool_name='restormer', subtask=subtask, work_dir='Restormer', script_rel_path='demo.py')
+        opt_dict = SUBTASK_TO_TASK      # multitask_tools.py:151-156
+        self.opt_task = opt_dict[canonical_subtask(subtask)]
+        self._cache = cache
+        self.tile, self.tile_overlap = tile, tile_overlap
+
+    def _get_cmd_opts(self) -> list:
+        """Kept for introspection parity (multitask_tools.py:159-165); not used to spawn anything."""
+        return ["--task", self.opt_task, "--input_dir", self.input_dir, "--result_dir", self.output_dir]
+
+    def _invoke(self, *args) -> None:
+        self._preprocess()
+        cache = self._cache or default_cache()
+        be = cache.get(self.opt_task)
+        src = sorted(Path(self.input_dir).glob('*'))[0]
+        gray = self.opt_task == 'Gaussian_Gray_Denoising'
+        img = read_image(src, gray=gray)
+        out = be.restore(img, tile=self.tile, tile_overlap=self.tile_overlap)
+        # demo.py writes {result_dir}/{task}/{stem}.png and multitask_tools.py:167-173 moves it to output.png
+        write_png(Path(self.output_dir) / 'output.png', out)
+        self._postprocess()
+
+
+class Executor:
+    """Registry of toolboxes (executor/__init__.py:24-94,161-169)."""
+
+    def __init__(self):
+        self.toolbox_router: dict = {}
+        self._executed_subtask_cnt: int = 0
+
+    def register_subtask(self, subtask_name, subtask_toolbox) -> None:
+        self.toolbox_router[subtask_name] = subtask_toolbox
+
+    @property
+    def subtasks(self) -> set:
+        return set(self.toolbox_router.keys())
+
+    @property
+    def executed_subtask_cnt(self) -> int:
+        return self._executed_subtask_cnt
+
+    def execute_subtask(self, subtask: str, input_path: Path) -> Path:
+        """executor/__init__.py:40-85: runs every tool of the subtask, directory protocol unchanged."""
+        input_path = Path(input_path)
+        self._executed_subtask_cnt += 1
+        subtask_dir = input_path.parents[1] / f"subtask{self._executed_subtask_cnt}-{subtask.replace(' ', '_')}"
+        subtask_dir.mkdir()
+        toolbox = self.toolbox_router[subtask]
+        output_path = None
+        for tool_idx, tool in enumerate(toolbox, start=1):
+            tool_dir = subtask_dir / f'tool{tool_idx}-{tool.tool_name}'
+            output_dir = tool_dir / '0-img'
+            output_dir.mkdir(parents=True)
+            tool(input_dir=input_path.parent, output_dir=output_dir)
+            output_path = list(output_dir.glob('*'))[0]
+        return output_path
+
+    def invoke_a_tool(self, subtask_name: str, tool_name: str, input_dir: Path, output_dir: Path):
+        """executor/__init__.py:87-94."""
+        for tool in self.toolbox_router[subtask_name]:
+            if tool.tool_name == tool_name:
+                tool(Path(input_dir), Path(output_dir))
+                return
+
+
+# subtask keys exactly as the reference registers them (executor/__init__.py:162-169)
+RESTORMER_SUBTASKS = {
+    'denoising': 'denoising',
+    'motion deblurring': 'motion_deblurring',
+    'defocus deblurring': 'defocus_deblurring',
+    'deraining': 'deraining',
+}
+
+
+def build_executor(cache: Optional[BackendCache] = None) -> Executor:
+    ex = Executor()
+    for key, sub in RESTORMER_SUBTASKS.items():
+        ex.register_subtask(key, [Restormer(subtask=sub, cache=cache)])
+    return ex
+
+
+def install_into(reference_executor, cache: Optional[BackendCache] = None) -> int:
+    """Drop-in: replace every tool named 'restormer' in an existing (reference) executor's toolboxes by the
+    HIP-backed tool, leaving all other tools and the LLM orchestration untouched.  Returns the count."""
+    n = 0
+    for key, toolbox in reference_executor.toolbox_router.items():
+        for i, tool in enumerate(toolbox):
+            if getattr(tool, 'tool_name', None) == 'restormer':
+                toolbox[i] = Restormer(subtask=canonical_subtask(getattr(tool, 'subtask', key)), cache=cache)
+                n += 1
+    return n
+
+
+executor = build_executor()     # singleton, like executor/__init__.py:160-169 (backends are created lazily)

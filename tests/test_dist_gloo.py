@@ -1,0 +1,107 @@
+"""Multi-rank tile-parallel path (ira_amd/dist.py) on CPU with the gloo backend, world_size 2 and 3:
+partition + all-gather + row-major blend must reproduce the single-process reference tiler
+(demo.py:132-153) bit for bit.  The per-tile 'network' is a cheap deterministic stand-in; the real
+kernels are covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from ira_amd.dist import TileParallelRestorer, block_partition
+from oracle import restormer_oracle as O
+
+
+def fake_net(t):                      # (n, th, tw, c) float32 -> same shape; depends on the whole tile (like attention)
+    return t * 0.75 + 0.1 * t.mean(dim=(1, 2, 3), keepdim=True) + 0.05
+
+
+def py_plan(h, w, tile, overlap):
+    padh, padw = O.pad_amounts(h, w)
+    Hp, Wp = h + padh, w + padw
+    if not tile:
+        return Hp, Wp, Hp, Wp, 1, 1
+    t = min(tile, Hp, Wp)
+    s = t - overlap
+    return Hp, Wp, t, t, len(O.tile_index_list(Hp, t, s)), len(O.tile_index_list(Wp, t, s))
+
+
+class CpuTileBackend:
+    """restore_tiles_t / blend_tiles_t with the arithmetic of csrc k_extract_tiles / k_blend in torch."""
+
+    def _geom(self, h, w, tile, overlap):
+        Hp, Wp, th, tw, nr, nc = py_plan(h, w, tile, overlap)
+        hi = O.tile_index_list(Hp, th, th - overlap) if tile else [0]
+        wi = O.tile_index_list(Wp, tw, tw - overlap) if tile else [0]
+        return Hp, Wp, th, tw, hi, wi
+
+    def restore_tiles_t(self, frame, h, w, c, tile, overlap, first, n, out):
+        Hp, Wp, th, tw, hi, wi = self._geom(h, w, tile, overlap)
+        x = frame.float().div(255.).permute(2, 0, 1).unsqueeze(0)
+        x = torch.nn.functional.pad(x, (0, Wp - w, 0, Hp - h), 'reflect')[0].permute(1, 2, 0)
+        origins = [(y, xx) for y in hi for xx in wi][first:first + n]
+        tiles = torch.stack([x[y:y + th, xx:xx + tw] for y, xx in origins])
+        out[:n] = fake_net(tiles)
+
+    def blend_tiles_t(self, tiles, h, w, c, tile, overlap, out):
+        Hp, Wp, th, tw, hi, wi = self._geom(h, w, tile, overlap)
+        E = torch.zeros(Hp, Wp, c); Wt = torch.zeros(Hp, Wp, c)
+        k = 0
+        for y in hi:
+            for xx in wi:
+                E[y:y + th, xx:xx + tw] += tiles[k]; Wt[y:y + th, xx:xx + tw] += 1; k += 1
+        out.copy_(torch.from_numpy(O.img_as_ubyte(torch.clamp(E / Wt, 0, 1)[:h, :w].numpy())))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, h, w, tile, overlap, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _, noisy = O.synthetic_noisy_image(h, w, 3, seed=5)
+    rst = TileParallelRestorer(CpuTileBackend(), rank, world, plan_fn=py_plan)
+    out = rst.restore_frame(torch.from_numpy(noisy), tile, overlap)
+    out2 = rst.restore_frame(torch.from_numpy(noisy), tile, overlap)     # buffers are reused across frames
+    assert torch.equal(out, out2)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,h,w,tile,overlap', [(2, 150, 203, 64, 16), (3, 97, 130, 48, 8), (2, 70, 100, 512, 32)])
+def test_tile_parallel_matches_single_process(world, h, w, tile, overlap):
+    _, noisy = O.synthetic_noisy_image(h, w, 3, seed=5)
+    single = TileParallelRestorer(CpuTileBackend(), 0, 1, plan_fn=py_plan).restore_frame(torch.from_numpy(noisy), tile, overlap).numpy()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, tile, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert np.array_equal(results[r], single), r
+
+
+def test_block_partition_covers_in_order():
+    for n in (1, 5, 6, 40, 41):
+        for world in (1, 2, 3, 4, 8):
+            got = []
+            chunk = None
+            for r in range(world):
+                first, count, chunk = block_partition(n, world, r)
+                assert count <= chunk
+                got += list(range(first, first + count))
+            assert got == list(range(n))
+    assert block_partition(40, 8, 3) == (15, 5, 5)      # 5 tiles per GPU at 4K on 8 GPUs

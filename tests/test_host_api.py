@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's tool / registry / service API (no GPU: a fake backend stands in
+for RestormerBackend).  Reference behaviour: AgenticIR/executor/tool.py:33-62, executor/__init__.py:24-94,
+multitask_tools.py:136-173, AgentApp/model_service/denoising/Restormer/model_serving.py:55-209."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from ira_amd import tools as T
+from ira_amd import service as S
+from ira_amd.config import SUPPORTED_TASKS, task_config
+
+
+class FakeBackend:
+    calls = []
+
+    def __init__(self, cfg, sd, device):
+        self.cfg = cfg
+
+    def restore(self, img, tile=None, tile_overlap=32):
+        FakeBackend.calls.append((img.shape, tile, tile_overlap))
+        return (255 - img).astype(np.uint8)
+
+    def close(self):
+        pass
+
+
+@pytest.fixture()
+def cache():
+    FakeBackend.calls = []
+    return T.BackendCache(device=0, state_dict_loader=lambda task, wd=None: {}, backend_factory=FakeBackend)
+
+
+def _img(h=21, w=30, c=3, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, c), dtype=np.uint8)
+
+
+def test_tool_contract(tmp_path, cache):
+    inp, out = tmp_path / 'in', tmp_path / 'out'
+    inp.mkdir(); out.mkdir()
+    img = _img()
+    Image.fromarray(img).save(inp / 'input.png')
+    tool = T.Restormer(subtask='denoising', cache=cache)
+    assert tool.tool_name == 'restormer' and tool.subtask == 'denoising' and tool.opt_task == 'Real_Denoising'
+    tool(inp, out, silent=True)
+    assert os.listdir(out) == ['output.png']                      # tool.py:56-62
+    got = np.asarray(Image.open(out / 'output.png'))
+    assert np.array_equal(got, 255 - img)
+    assert FakeBackend.calls == [((21, 30, 3), None, 32)]         # whole-image mode: no --tile (multitask_tools.py:159-165)
+    # output dir must be empty, input dir must hold exactly one file (tool.py:51-54)
+    with pytest.raises(AssertionError):
+        tool(inp, out, silent=True)
+    (inp / 'second.png').write_bytes((inp / 'input.png').read_bytes())
+    out2 = tmp_path / 'out2'; out2.mkdir()
+    with pytest.raises(AssertionError):
+        tool(inp, out2, silent=True)
+
+
+@pytest.mark.parametrize('subtask,task', [('denoising', 'Real_Denoising'), ('motion_deblurring', 'Motion_Deblurring'),
+                                          ('defocus_deblurring', 'Single_Image_Defocus_Deblurring'), ('deraining', 'Deraining'),
+                                          ('motion deblurring', 'Motion_Deblurring')])
+def test_subtask_to_task(subtask, task, cache):
+    assert T.Restormer(subtask=subtask, cache=cache).opt_task == task      # multitask_tools.py:151-156
+
+
+def test_executor_registry_and_directory_protocol(tmp_path, cache):
+    ex = T.build_executor(cache)
+    assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining'}
+    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['restormer']
+    root = tmp_path / 'task'
+    (root / '0-img').mkdir(parents=True)
+    img = _img(seed=3)
+    Image.fromarray(img).save(root / '0-img' / 'input.png')
+    outp = ex.execute_subtask('motion deblurring', root / '0-img' / 'input.png')     # executor/__init__.py:40-85
+    assert outp == root / 'subtask1-motion_deblurring' / 'tool1-restormer' / '0-img' / 'output.png'
+    assert ex.executed_subtask_cnt == 1
+    o2 = tmp_path / 'o2'; o2.mkdir()
+    ex.invoke_a_tool('denoising', 'restormer', root / '0-img', o2)
+    assert (o2 / 'output.png').exists()
+
+
+def test_install_into_reference_executor(cache):
+    class RefTool:
+        def __init__(self, name, subtask):
+            self.tool_name, self.subtask = name, subtask
+
+    class RefExecutor:
+        toolbox_router = {'denoising': [RefTool('xrestormer', 'denoising'), RefTool('restormer', 'denoising')],
+                          'dehazing': [RefTool('maxim', 'dehazing')]}
+    n = T.install_into(RefExecutor, cache)
+    assert n == 1
+    tb = RefExecutor.toolbox_router['denoising']
+    assert tb[0].tool_name == 'xrestormer' and isinstance(tb[1], T.Restormer) and tb[1].opt_task == 'Real_Denoising'
+
+
+def test_service_api(cache):
+    svc = S.RestormerService(task='Real_Denoising', weight_dir='/w', cache=cache)
+    path, params = svc.get_weights_and_parameters('Gaussian_Gray_Denoising')   # model_serving.py:64-98
+    assert path == '/w/gaussian_gray_denoising_blind.pth'
+    assert params['inp_channels'] == 1 and params['out_channels'] == 1 and params['LayerNorm_type'] == 'BiasFree'
+    assert svc.get_weights_and_parameters('Deraining')[1]['LayerNorm_type'] == 'WithBias'
+    with pytest.raises(ValueError):
+        svc.get_weights_and_parameters('nope')
+    img = _img(17, 23)
+    buf = io.BytesIO(); Image.fromarray(img).save(buf, format='PNG')
+    out = svc.restore_image(buf.getvalue(), 'Real_Denoising', tile=64, tile_overlap=16)
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(out))), 255 - img)
+    assert FakeBackend.calls[-1] == ((17, 23, 3), 64, 16)
+    assert list(svc.models.keys()) == ['Real_Denoising']
+    # gray task decodes to one channel (model_serving.py:160-161)
+    g = svc.restore_image(buf.getvalue(), 'Gaussian_Gray_Denoising')
+    assert np.asarray(Image.open(io.BytesIO(g))).ndim == 2
+    assert S.allowed_file('a.PNG') and not S.allowed_file('a.gif')
+
+
+def test_restore_alias(cache):
+    img = _img(9, 8)
+    assert np.array_equal(S.restore(img, task='denoising', cache=cache), 255 - img)
+    assert np.array_equal(S.restore(Image.fromarray(img), task='Deraining', cache=cache), 255 - img)
+    with pytest.raises(ValueError):
+        S.restore(img, task='colorize', cache=cache)
+    with pytest.raises(ValueError):
+        S.restore(img, tool='swinir', cache=cache)
+
+
+def test_task_table_matches_reference():
+    # demo.py:52-70: BiasFree for the three denoising tasks, 1 channel for gray
+    for t in SUPPORTED_TASKS:
+        cfg = task_config(t)
+        assert (cfg.LayerNorm_type == 'BiasFree') == ('Denoising' in t)
+        assert cfg.inp_channels == (1 if t == 'Gaussian_Gray_Denoising' else 3)
+        assert (cfg.dim, cfg.num_blocks, cfg.heads, cfg.num_refinement_blocks, cfg.bias) == (48, [4, 6, 6, 8], [1, 2, 4, 8], 4, False)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The C-ABI library loads here (no GPU) and exports every entry point include/ira.h declares."""
+    from ira_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'ira.h')).read()
+    declared = set(re.findall(r'\b(ira_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'ira_restormer_config'}
+    lib = _capi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    # host-only entry point works without a device: the 4K plan of SURVEY 8a2
+    assert _capi.tile_plan(2160, 3840, 512, 32) == (2160, 3840, 512, 512, 5, 8)
+    assert _capi.tile_plan(75, 91, None, 32) == (80, 96, 80, 96, 1, 1)
+    assert _capi.tile_plan(70, 100, 512, 32) == (72, 104, 72, 72, 1, 2)
+    with pytest.raises(_capi.IraError):
+        _capi.tile_plan(100, 100, 60, 32)          # "tile size should be multiple of 8" (demo.py:136)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from ira_amd._capi import IraError
+    from ira_amd.backend import RestormerBackend
+    from ira_amd.config import reduced_config
+    from ira_amd.weights import seeded_state_dict
+    cfg = reduced_config()
+    with pytest.raises(IraError):
+        RestormerBackend(cfg, seeded_state_dict(cfg, 0))
