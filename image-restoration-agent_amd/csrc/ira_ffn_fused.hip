@@ -4,15 +4,19 @@
 // Hf tensor never leave the CU: HBM traffic of the FFN drops from ~4.2 KB/px (three kernels) to
 // ~0.9 KB/px (x in with a 1-pixel halo, x out), at the price of recomputing project_in on the halo.
 //
-// One workgroup (512 threads = 8 waves) owns an 8 x 32 output patch of one tile:
-//   step 1   LN(x) of the 10 x 34 halo patch -> fp16 MFMA B-fragments in LDS (fragment-major, 1 KB / (group, k-step))
-//   per hidden chunk j (32 channels of x1 + the matching 32 of x2):
-//     2a     hp[halo px][64] = W_in[chunk] . LN(x)        MFMA, 11 pixel groups over 8 waves -> LDS (fp16, zero outside
-//                                                         the image = the dwconv's zero padding)
-//     2b     wave w = output row w: depthwise 3x3 on x1/x2 from LDS, exact-erf GELU gate, result straight into the
-//            B-fragment registers of
-//     2c     acc_out += W_out[:, chunk] . g               MFMA
-//   step 3   x_out = acc_out (+bias) + x                   fp32 store
+// One workgroup = 8 waves owns an 8 x 32 output patch (10 x 34 halo = 340 px = 11 groups of 32) and is
+// WAVE-SPECIALISED; wave i and wave i+4 share a SIMD, so every SIMD runs one producer (MFMA) and one consumer
+// (VALU) and the two pipes overlap:
+//   producers (waves 0-3)  keep the LayerNorm-ed fp16 B-fragments of their <= 3 halo groups in REGISTERS for the
+//                          whole kernel and, per hidden chunk j (32 channels of x1 + the matching 32 of x2),
+//                          compute hp[j] = W_in[chunk] . LN(x) (MFMA) into an LDS double buffer, one chunk ahead
+//                          (zeros outside the image = the depthwise conv's zero padding);
+//   consumers (waves 4-7)  own two output rows each.  Lane (r, h) handles pixel x0+r of BOTH rows for the channel
+//                          octet (s, h) of the chunk, i.e. exactly its slot of the MFMA B-fragment: the depthwise
+//                          weights (fp32, staged per chunk in LDS by the producers) are read once per two
+//                          outputs, the gated values land directly in B-fragment registers (no shuffle), then
+//                          acc_out += W_out[:, chunk] . g (MFMA) for both rows;
+//   one __syncthreads() per chunk; epilogue x_out = acc_out (+bias) + x in fp32.
 // x_out must not alias x (neighbouring patches read each other's halo).
 // Numerics contract identical to the three-kernel path (ira_kernels.hip): fp16 LN output, fp16 hidden (hp) and gated
 // (g) values, weights as fp16 hi+lo planes, fp32 accumulation / LN statistics / dwconv / GELU.
@@ -24,6 +28,7 @@ typedef _Float16 f16;
 typedef f16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define IRA_DEV __device__ __forceinline__
 
@@ -45,22 +50,35 @@ IRA_DEV float gelu_erf_f(float x) {   // same formulation as ira_kernels.hip
     return 0.5f * x * ((x >= 0.f) ? (2.0f - e) : e);
 }
 
+// acc += (float)half(lo/hi 16 bits of `packed`) * w     -- v_fma_mix_f32: fp16 source 0, fp32 sources 1 and 2.
+// One instruction instead of v_cvt_f32_f16 + v_fma_f32 (the converts were half of the VALU work of the depthwise
+// conv and kept 32 extra registers live).
+IRA_DEV void fma_mix_lo(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+}
+IRA_DEV void fma_mix_hi(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+}
+IRA_DEV void dw_tap(float (&acc)[8], const u32x4 v, const f32x4 wl, const f32x4 wh) {
+    fma_mix_lo(acc[0], v[0], wl[0]); fma_mix_hi(acc[1], v[0], wl[1]);
+    fma_mix_lo(acc[2], v[1], wl[2]); fma_mix_hi(acc[3], v[1], wl[3]);
+    fma_mix_lo(acc[4], v[2], wh[0]); fma_mix_hi(acc[5], v[2], wh[1]);
+    fma_mix_lo(acc[6], v[3], wh[2]); fma_mix_hi(acc[7], v[3], wh[3]);
+}
+
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PHW = PH * PW;   // 340 halo pixels
 constexpr int NG1 = (PHW + 31) / 32;                                        // 11 pixel groups
 constexpr int HPS = 72;                                                     // hp row stride in halfs (64 + 8 pad)
-
-template <int C>
-struct FfnLds {
-    static constexpr int KS = C / 16;
-    static constexpr size_t xn_bytes = (size_t)NG1 * KS * 64 * 16;
-    static constexpr size_t hp_bytes = (size_t)NG1 * 32 * HPS * 2;
-    static constexpr size_t dw_bytes = 9 * 64 * 4;
-    static constexpr size_t total = xn_bytes + hp_bytes + dw_bytes;
-};
+constexpr int HP_ROWS = NG1 * 32;
+constexpr size_t HP_BYTES = (size_t)HP_ROWS * HPS * 2;                      // one hp buffer: 50 688 B
+constexpr size_t DW_BYTES = 9 * 64 * 4;                                    // depthwise weights of one chunk, fp32 [9][64]
+constexpr size_t FFN_LDS = 2 * HP_BYTES + 2 * DW_BYTES;                     // double buffers: 105 984 B
 
 }  // namespace
 
-template <int C, int LN>
+// BIN: project_in has a bias (LayerNorm bias folded and/or conv bias); CB: depthwise / project_out biases present
+// (cfg.bias, never set by the reference tasks).  Compile-time so that the hot loops carry no per-element branches.
+template <int C, int LN, bool BIN, bool CB>
 __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, float* __restrict__ xo,
                                                    const f16* __restrict__ Win, const float* __restrict__ bin,
                                                    const float* __restrict__ dww, const float* __restrict__ dwb,
@@ -69,9 +87,8 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
     constexpr int KS = C / 16;            // k-steps of project_in
     constexpr int NBC = (C + 31) / 32;    // 32-row blocks of project_out
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half8* xn = (half8*)smem;                                              // [NG1][KS][64]
-    f16* hp = (f16*)(smem + FfnLds<C>::xn_bytes);                          // [NG1*32][HPS]
-    float* dwl = (float*)(smem + FfnLds<C>::xn_bytes + FfnLds<C>::hp_bytes);   // [9][64]
+    f16* hpbuf = (f16*)smem;                                  // [2][HP_ROWS][HPS]
+    float* dwbuf = (float*)(smem + 2 * HP_BYTES);             // [2][9][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
@@ -80,191 +97,239 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
     const int py = (int)((pid / npx) % npy), pxx = (int)(pid % npx);
     const int y0 = py * TH, x0 = pxx * TW;
     const float* xt = x + (long)t * H * W * C;
+    const int NBH = Hp >> 5;              // 32-channel chunks of x1 (= of x2)
 
-    // ---- step 1: LN of the halo patch -> B fragments in LDS
-    for (int g = wave; g < NG1; g += 8) {
-        const int q = 32 * g + r;
-        const int hy = q / PW, hx = q - hy * PW;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float* src = xt + ((long)(in ? yy : 0) * W + (in ? xx : 0)) * C + 8 * h;
-        float xv[KS][8];
+    if (wave < 4) {
+        // =========================== producers ===========================
+        constexpr int MAXG = 3;
+        half8 b[MAXG][KS];
+        bool inimg[MAXG];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += xv[s][j];
-        sum += __shfl_xor(sum, 32);
-        const float mu = sum * (1.0f / C);
-        float sq = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
-        const float sub = (LN == 2) ? mu : 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            half8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)((xv[s][j] - sub) * rstd);
-            xn[(g * KS + s) * 64 + lane] = o;
-        }
-    }
-
-    // this wave's output row (step 2b/2c/3): pixels (y0 + wave, x0 + r)
-    const int oy = y0 + wave, ox = x0 + r;
-    const bool ovalid = oy < H && ox < W;
-    f32x16 acc_out[NBC];
-#pragma unroll
-    for (int nb = 0; nb < NBC; ++nb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc_out[nb][j] = 0.f;
-
-    const int NBH = Hp >> 5;                       // 32-channel chunks of x1 (= of x2)
-    const int KTO = Hp >> 4;                       // k-steps of project_out
-    const long win_lo = (long)(2 * NBH) * KS * 512;
-    const long wout_lo = (long)NBC * KTO * 512;
-    const f16* winl = Win + lane * 8;
-    const f16* woutl = Wout + lane * 8;
-
-    for (int j = 0; j < NBH; ++j) {
-        __syncthreads();     // xn complete (first pass) / previous chunk's readers of hp and dwl done
-        // depthwise weights of this chunk: [9][64] (x1 channels 0..31, x2 channels 32..63)
-        for (int i = tid; i < 9 * 64; i += 512) {
-            const int tap = i >> 6, cc = i & 63;
-            const int ch = (cc < 32) ? (32 * j + cc) : (Hp + 32 * j + cc - 32);
-            dwl[i] = dww[(long)tap * 2 * Hp + ch];
-        }
-        // ---- 2a: hp chunk = W_in[chunk] . LN(x) on every halo pixel group
-        for (int g = wave; g < NG1; g += 8) {
-            f32x16 a1, a2;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int cl = 16 * u + 8 * h + e;
-                    a1[8 * u + e] = bin ? bin[32 * j + cl] : 0.f;
-                    a2[8 * u + e] = bin ? bin[Hp + 32 * j + cl] : 0.f;
-                }
-            const f16* w1 = winl + (long)j * KS * 512;
-            const f16* w2 = winl + (long)(NBH + j) * KS * 512;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const half8 b = xn[(g * KS + s) * 64 + lane];
-                const half8 a1h = *(const half8*)(w1 + s * 512), a1l = *(const half8*)(w1 + win_lo + s * 512);
-                const half8 a2h = *(const half8*)(w2 + s * 512), a2l = *(const half8*)(w2 + win_lo + s * 512);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b, a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b, a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h, b, a2, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2l, b, a2, 0, 0, 0);
-            }
+        for (int gi = 0; gi < MAXG; ++gi) {
+            const int g = wave + 4 * gi;
             const int q = 32 * g + r;
             const int hy = q / PW, hx = q - hy * PW;
             const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            f16* dst = hp + (long)q * HPS + 8 * h;
+            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* src = xt + ((long)(inimg[gi] ? yy : 0) * W + (inimg[gi] ? xx : 0)) * C + 8 * h;
+            float xv[KS][8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                half8 o1, o2;
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    o1[e] = in ? (f16)a1[8 * u + e] : (f16)0.f;     // zero padding of the depthwise conv
-                    o2[e] = in ? (f16)a2[8 * u + e] : (f16)0.f;
-                }
-                *(half8*)(dst + 16 * u) = o1;
-                *(half8*)(dst + 32 + 16 * u) = o2;
+                for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
             }
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += xv[s][j];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+            const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[gi][s][j] = (f16)((xv[s][j] - sub) * rstd);
         }
-        __syncthreads();
-        // ---- 2b + 2c: depthwise 3x3 + gate on this wave's output row, then project_out accumulation
+        const long win_lo = (long)(2 * NBH) * KS * 512;
+        const f16* winl = Win + lane * 8;
+        const int ngroups = (wave + 8 < NG1) ? 3 : 2;
+
+        for (int j = 0; j <= NBH; ++j) {
+            if (j < NBH) {
+                // W_in fragments of chunk j: rows [32j, 32j+32) (x1) and Hp + [32j, 32j+32) (x2), hi and lo planes
+                half8 a1h[KS], a1l[KS], a2h[KS], a2l[KS];
+                const f16* w1 = winl + (long)j * KS * 512;
+                const f16* w2 = winl + (long)(NBH + j) * KS * 512;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int cl0 = 16 * s + 8 * h;
-            float d1[8], d2[8];
+                for (int s = 0; s < KS; ++s) {
+                    a1h[s] = *(const half8*)(w1 + s * 512); a1l[s] = *(const half8*)(w1 + win_lo + s * 512);
+                    a2h[s] = *(const half8*)(w2 + s * 512); a2l[s] = *(const half8*)(w2 + win_lo + s * 512);
+                }
+                f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+                float* dwl = dwbuf + (j & 1) * 576;
+                for (int i = tid; i < 576; i += 256) {          // tid < 256 here: the four producer waves
+                    const int tap = i >> 6, cc = i & 63;
+                    const int ch = (cc < 32) ? (32 * j + cc) : (Hp + 32 * j + cc - 32);
+                    dwl[i] = dww[(long)tap * 2 * Hp + ch];
+                }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                d1[e] = dwb ? dwb[32 * j + cl0 + e] : 0.f;
-                d2[e] = dwb ? dwb[Hp + 32 * j + cl0 + e] : 0.f;
-            }
+                for (int gi = 0; gi < MAXG; ++gi) {
+                    if (gi >= ngroups) break;
+                    f32x16 a1, a2;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int q = (wave + tap / 3) * PW + r + tap % 3;       // halo index of (oy + dy, ox + dx)
-                const half8 v1 = *(const half8*)(hp + (long)q * HPS + cl0);
-                const half8 v2 = *(const half8*)(hp + (long)q * HPS + 32 + cl0);
-                const f32x4 wa = *(const f32x4*)(dwl + tap * 64 + cl0), wb = *(const f32x4*)(dwl + tap * 64 + cl0 + 4);
-                const f32x4 wc = *(const f32x4*)(dwl + tap * 64 + 32 + cl0), wd = *(const f32x4*)(dwl + tap * 64 + 32 + cl0 + 4);
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    d1[e] = fmaf((float)v1[e], wa[e], d1[e]);
-                    d1[4 + e] = fmaf((float)v1[4 + e], wb[e], d1[4 + e]);
-                    d2[e] = fmaf((float)v2[e], wc[e], d2[e]);
-                    d2[4 + e] = fmaf((float)v2[4 + e], wd[e], d2[4 + e]);
+                        for (int e = 0; e < 8; ++e) {
+                            const int cl = 16 * u + 8 * h + e;
+                            a1[8 * u + e] = BIN ? bin[32 * j + cl] : 0.f;
+                            a2[8 * u + e] = BIN ? bin[Hp + 32 * j + cl] : 0.f;
+                        }
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[s], b[gi][s], a1, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[s], b[gi][s], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[s], b[gi][s], a2, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2l[s], b[gi][s], a2, 0, 0, 0);
+                    }
+                    const int q = 32 * (wave + 4 * gi) + r;
+                    f16* dst = hp + (long)q * HPS + 8 * h;
+                    const bool in = inimg[gi];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        half8 o1, o2;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            o1[e] = in ? (f16)a1[8 * u + e] : (f16)0.f;     // zero padding of the depthwise conv
+                            o2[e] = in ? (f16)a2[8 * u + e] : (f16)0.f;
+                        }
+                        *(half8*)(dst + 16 * u) = o1;
+                        *(half8*)(dst + 32 + 16 * u) = o2;
+                    }
                 }
             }
-            half8 bg;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bg[e] = (f16)(gelu_erf_f(d1[e]) * d2[e]);
-            const int ks = 2 * j + s;
-#pragma unroll
-            for (int nb = 0; nb < NBC; ++nb) {
-                const half8 ah = *(const half8*)(woutl + ((long)nb * KTO + ks) * 512);
-                const half8 al = *(const half8*)(woutl + wout_lo + ((long)nb * KTO + ks) * 512);
-                acc_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bg, acc_out[nb], 0, 0, 0);
-                acc_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bg, acc_out[nb], 0, 0, 0);
-            }
+            __syncthreads();      // hp[j] visible to the consumers; they have finished with hp[j-1]
         }
+        return;
     }
 
-    // ---- step 3: residual + store
-    if (!ovalid) return;
-    const long po = ((long)t * H + oy) * W + ox;
+    // =========================== consumers ===========================
+    const int cw = wave - 4;                      // rows 2cw and 2cw+1 of the patch
+    const int KTO = Hp >> 4;                      // k-steps of project_out
+    const long wout_lo = (long)NBC * KTO * 512;
+    const f16* woutl = Wout + lane * 8;
+    f32x16 accA[NBC], accB[NBC];                  // row 2cw / row 2cw+1: lane (r, h) owns channels 32nb+16u+8h+e of pixel r
 #pragma unroll
     for (int nb = 0; nb < NBC; ++nb)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n0 = 32 * nb + 16 * u + 8 * h;
-            if (n0 + 8 <= C) {
-                f32x4 lo = *(const f32x4*)(x + po * C + n0), hi = *(const f32x4*)(x + po * C + n0 + 4);
+        for (int e = 0; e < 16; ++e) { accA[nb][e] = 0.f; accB[nb][e] = 0.f; }
+
+    __syncthreads();                              // hp[0], dw[0] ready
+    for (int j = 0; j < NBH; ++j) {
+        const f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+        const float* dwl = dwbuf + (j & 1) * 576;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] += acc_out[nb][8 * u + e] + (bout ? bout[n0 + e] : 0.f);
-                    hi[e] += acc_out[nb][8 * u + 4 + e] + (bout ? bout[n0 + 4 + e] : 0.f);
-                }
-                *(f32x4*)(xo + po * C + n0) = lo;
-                *(f32x4*)(xo + po * C + n0 + 4) = hi;
+        for (int s = 0; s < 2; ++s) {
+            const int cl0 = 16 * s + 8 * h;       // this lane's channel octet inside the chunk
+            // W_out fragments of k-step 2j+s: issued before the VALU phase, consumed after it
+            half8 woh[NBC], wol[NBC];
+#pragma unroll
+            for (int nb = 0; nb < NBC; ++nb) {
+                woh[nb] = *(const half8*)(woutl + ((long)nb * KTO + 2 * j + s) * 512);
+                wol[nb] = *(const half8*)(woutl + wout_lo + ((long)nb * KTO + 2 * j + s) * 512);
+            }
+            float a1[8], a2[8], b1[8], b2[8];     // x1 / x2 accumulators of row A and row B
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a1[e] = CB ? dwb[32 * j + cl0 + e] : 0.f;  b1[e] = a1[e];
+                a2[e] = CB ? dwb[Hp + 32 * j + cl0 + e] : 0.f;  b2[e] = a2[e];
+            }
+            // tap loop, software-pipelined by one tap: the LDS reads of tap+1 are issued before the FMAs of tap
+            struct TapIn { f32x4 w1l, w1h, w2l, w2h; u32x4 vA1, vA2, vB1, vB2; };
+            auto load_tap = [&](int tap) {
+                TapIn ti;
+                ti.w1l = *(const f32x4*)(dwl + tap * 64 + cl0);      ti.w1h = *(const f32x4*)(dwl + tap * 64 + cl0 + 4);
+                ti.w2l = *(const f32x4*)(dwl + tap * 64 + 32 + cl0); ti.w2h = *(const f32x4*)(dwl + tap * 64 + 32 + cl0 + 4);
+                const int qa = (2 * cw + tap / 3) * PW + r + tap % 3;      // halo index of (row A + dy, x + dx)
+                ti.vA1 = *(const u32x4*)(hp + (long)qa * HPS + cl0);
+                ti.vA2 = *(const u32x4*)(hp + (long)qa * HPS + 32 + cl0);
+                ti.vB1 = *(const u32x4*)(hp + (long)(qa + PW) * HPS + cl0);
+                ti.vB2 = *(const u32x4*)(hp + (long)(qa + PW) * HPS + 32 + cl0);
+                return ti;
+            };
+            TapIn cur = load_tap(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                TapIn nxt = cur;
+                if (tap < 8) nxt = load_tap(tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_tap(a1, cur.vA1, cur.w1l, cur.w1h);
+                dw_tap(a2, cur.vA2, cur.w2l, cur.w2h);
+                dw_tap(b1, cur.vB1, cur.w1l, cur.w1h);
+                dw_tap(b2, cur.vB2, cur.w2l, cur.w2h);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+            half8 fA, fB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fA[e] = (f16)(gelu_erf_f(a1[e]) * a2[e]); fB[e] = (f16)(gelu_erf_f(b1[e]) * b2[e]); }
+#pragma unroll
+            for (int nb = 0; nb < NBC; ++nb) {
+                accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh[nb], fA, accA[nb], 0, 0, 0);
+                accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol[nb], fA, accA[nb], 0, 0, 0);
+                accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh[nb], fB, accB[nb], 0, 0, 0);
+                accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol[nb], fB, accB[nb], 0, 0, 0);
             }
         }
+        __syncthreads();          // done with hp[j] / dw[j]; hp[j+1] / dw[j+1] are ready
+    }
+
+    // ---- epilogue: x_out = x + acc (+ bias), fp32
+#pragma unroll
+    for (int rowsel = 0; rowsel < 2; ++rowsel) {
+        const int oyy = y0 + 2 * cw + rowsel, oxx = x0 + r;
+        if (oyy >= H || oxx >= W) continue;
+        const long po = ((long)t * H + oyy) * W + oxx;
+#pragma unroll
+        for (int nb = 0; nb < NBC; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 32 * nb + 16 * u + 8 * h;
+                if (n0 + 8 <= C) {
+                    f32x4 lo = *(const f32x4*)(x + po * C + n0), hi = *(const f32x4*)(x + po * C + n0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v0 = rowsel ? accB[nb][8 * u + e] : accA[nb][8 * u + e];
+                        const float v1 = rowsel ? accB[nb][8 * u + 4 + e] : accA[nb][8 * u + 4 + e];
+                        lo[e] += v0 + (CB ? bout[n0 + e] : 0.f);
+                        hi[e] += v1 + (CB ? bout[n0 + 4 + e] : 0.f);
+                    }
+                    *(f32x4*)(xo + po * C + n0) = lo;
+                    *(f32x4*)(xo + po * C + n0 + 4) = hi;
+                }
+            }
+    }
 }
 
 bool ffn_fused_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0; }
+
+template <int C, int LN, bool BIN, bool CB>
+static hipError_t ffn_launch2(hipStream_t st, const float* x, float* xo, const f16* Win, const float* bin, const float* dww,
+                              const float* dwb, const f16* Wout, const float* bout, int T, int H, int W, int Hp) {
+    const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<C, LN, BIN, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FFN_LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_ffn_fused<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(512), FFN_LDS, st, x, xo, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
+    return hipGetLastError();
+}
 
 template <int C>
 static hipError_t ffn_launch(hipStream_t st, const float* x, float* xo, int ln_mode, const f16* Win, const float* bin,
                              const float* dww, const float* dwb, const f16* Wout, const float* bout, int T, int H, int W,
                              int Hp) {
-    const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const size_t smem = FfnLds<C>::total;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_ffn_fused<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    const bool cb = dwb != nullptr && bout != nullptr;
+    if ((dwb != nullptr) != (bout != nullptr)) return hipErrorInvalidValue;
+#define IRA_FFN(LN_, BIN_, CB_) return ffn_launch2<C, LN_, BIN_, CB_>(st, x, xo, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp)
+    if (ln_mode == 1) {
+        if (bin) { if (cb) IRA_FFN(1, true, true); else IRA_FFN(1, true, false); }
+        else { if (cb) IRA_FFN(1, false, true); else IRA_FFN(1, false, false); }
+    } else {
+        if (bin) { if (cb) IRA_FFN(2, true, true); else IRA_FFN(2, true, false); }
+        else { if (cb) IRA_FFN(2, false, true); else IRA_FFN(2, false, false); }
     }
-    if (ln_mode == 1)
-        hipLaunchKernelGGL((k_ffn_fused<C, 1>), dim3((unsigned)nblk), dim3(512), smem, st, x, xo, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
-    else
-        hipLaunchKernelGGL((k_ffn_fused<C, 2>), dim3((unsigned)nblk), dim3(512), smem, st, x, xo, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
-    return hipGetLastError();
+#undef IRA_FFN
 }
 
 hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* xo, int ln_mode, int C, const void* Win, const float* bin,

@@ -44,7 +44,7 @@ class Contract:
 def GPU_CONTRACT():
     """What csrc/ implements: fp32 residual stream, fp16 branch activations, weights as fp16 hi + lo
     planes (~exact), dense 3x3 inputs split hi/lo in registers (~exact)."""
-    return Contract(res_fp16=False, act_fp16=True, off=['w', 'M', 'c3w', 'c3in'])
+    return Contract(res_fp16=False, act_fp16=True, off=['w', 'M', 'c3w', 'c3in', 'dw1w', 'dw2w'])
 
 
 def ln_core(x, ln_type):
@@ -91,7 +91,7 @@ def block(x, sd, p, heads, ln_type, ct: Contract):
     wq, bq = fold_ln(sd[f'{p}.attn.qkv.weight'], sd[f'{p}.norm1.body.weight'], lnb1, ct)
     xn = ct.act(ln_core(x, ln_type), 'xn1')
     qkv_pre = ct.act(conv1x1(xn, wq, bq), 'qkv_pre')
-    qkv = F.conv2d(qkv_pre, sd[f'{p}.attn.qkv_dwconv.weight'], padding=1, groups=3 * c)
+    qkv = F.conv2d(qkv_pre, ct.w(sd[f'{p}.attn.qkv_dwconv.weight'], 'dw1w'), padding=1, groups=3 * c)
     q, k, v = qkv.chunk(3, dim=1)
     q, k, v = ct.act(q, 'qk'), ct.act(k, 'qk'), ct.act(v, 'v')
     m = ct.w(attention_mix(q, k, sd[f'{p}.attn.temperature'], sd[f'{p}.attn.project_out.weight'], heads), 'M')
@@ -101,7 +101,7 @@ def block(x, sd, p, heads, ln_type, ct: Contract):
     wi, bi = fold_ln(sd[f'{p}.ffn.project_in.weight'], sd[f'{p}.norm2.body.weight'], lnb2, ct)
     xn = ct.act(ln_core(x, ln_type), 'xn2')
     hp = ct.act(conv1x1(xn, wi, bi), 'hp')
-    hd = F.conv2d(hp, sd[f'{p}.ffn.dwconv.weight'], padding=1, groups=hp.shape[1])
+    hd = F.conv2d(hp, ct.w(sd[f'{p}.ffn.dwconv.weight'], 'dw2w'), padding=1, groups=hp.shape[1])
     h1, h2 = hd.chunk(2, dim=1)
     g = ct.act(F.gelu(h1) * h2, 'g')
     x = ct.res(x + conv1x1(g, ct.w(sd[f'{p}.ffn.project_out.weight'][:, :, 0, 0])), 'res_ffn')
