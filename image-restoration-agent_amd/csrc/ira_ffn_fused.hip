@@ -143,60 +143,72 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
         const f16* winl = Win + lane * 8;
         const int ngroups = (wave + 8 < NG1) ? 3 : 2;
 
-        for (int j = 0; j <= NBH; ++j) {
-            if (j < NBH) {
-                // W_in fragments of chunk j: rows [32j, 32j+32) (x1) and Hp + [32j, 32j+32) (x2), hi and lo planes
-                half8 a1h[KS], a1l[KS], a2h[KS], a2l[KS];
-                const f16* w1 = winl + (long)j * KS * 512;
-                const f16* w2 = winl + (long)(NBH + j) * KS * 512;
+        // Only ONE workgroup fits a CU (LDS + registers), so nothing else hides this wave's global-load latency:
+        // the W_in fragments are prefetched half a chunk ahead (x1 rows load while x2 rows compute and vice
+        // versa) and the depthwise weights one chunk ahead, both in registers.
+        half8 p_h[KS], p_l[KS], q_h[KS], q_l[KS];     // x1 (rows 32j..) / x2 (rows Hp+32j..) fragments, hi+lo planes
+        auto load_frags = [&](half8 (&fh)[KS], half8 (&fl)[KS], int nbrow) {
+            const f16* w = winl + (long)nbrow * KS * 512;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { fh[s] = *(const half8*)(w + s * 512); fl[s] = *(const half8*)(w + win_lo + s * 512); }
+        };
+        float dwreg[3];
+        auto load_dw = [&](int j) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + 256 * k;              // tid < 256: the four producer waves
+                const int tap = i >> 6, cc = i & 63;
+                const int ch = (cc < 32) ? (32 * j + cc) : (Hp + 32 * j + cc - 32);
+                dwreg[k] = (i < 576) ? dww[(long)tap * 2 * Hp + ch] : 0.f;
+            }
+        };
+        load_frags(p_h, p_l, 0);
+        load_frags(q_h, q_l, NBH);
+        load_dw(0);
+
+        auto half_chunk = [&](const half8 (&fh)[KS], const half8 (&fl)[KS], f16* hp, int j, int xsel) {
+#pragma unroll
+            for (int gi = 0; gi < MAXG; ++gi) {
+                if (gi >= ngroups) break;
+                f32x16 acc;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[8 * u + e] = BIN ? bin[xsel * Hp + 32 * j + 16 * u + 8 * h + e] : 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    a1h[s] = *(const half8*)(w1 + s * 512); a1l[s] = *(const half8*)(w1 + win_lo + s * 512);
-                    a2h[s] = *(const half8*)(w2 + s * 512); a2l[s] = *(const half8*)(w2 + win_lo + s * 512);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s], b[gi][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s], b[gi][s], acc, 0, 0, 0);
                 }
-                f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
-                float* dwl = dwbuf + (j & 1) * 576;
-                for (int i = tid; i < 576; i += 256) {          // tid < 256 here: the four producer waves
-                    const int tap = i >> 6, cc = i & 63;
-                    const int ch = (cc < 32) ? (32 * j + cc) : (Hp + 32 * j + cc - 32);
-                    dwl[i] = dww[(long)tap * 2 * Hp + ch];
-                }
+                const int q = 32 * (wave + 4 * gi) + r;
+                f16* dst = hp + (long)q * HPS + 32 * xsel + 8 * h;
+                const bool in = inimg[gi];
 #pragma unroll
-                for (int gi = 0; gi < MAXG; ++gi) {
-                    if (gi >= ngroups) break;
-                    f32x16 a1, a2;
+                for (int u = 0; u < 2; ++u) {
+                    half8 o;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int cl = 16 * u + 8 * h + e;
-                            a1[8 * u + e] = BIN ? bin[32 * j + cl] : 0.f;
-                            a2[8 * u + e] = BIN ? bin[Hp + 32 * j + cl] : 0.f;
-                        }
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[s], b[gi][s], a1, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[s], b[gi][s], a1, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2h[s], b[gi][s], a2, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2l[s], b[gi][s], a2, 0, 0, 0);
-                    }
-                    const int q = 32 * (wave + 4 * gi) + r;
-                    f16* dst = hp + (long)q * HPS + 8 * h;
-                    const bool in = inimg[gi];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        half8 o1, o2;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            o1[e] = in ? (f16)a1[8 * u + e] : (f16)0.f;     // zero padding of the depthwise conv
-                            o2[e] = in ? (f16)a2[8 * u + e] : (f16)0.f;
-                        }
-                        *(half8*)(dst + 16 * u) = o1;
-                        *(half8*)(dst + 32 + 16 * u) = o2;
-                    }
+                    for (int e = 0; e < 8; ++e) o[e] = in ? (f16)acc[8 * u + e] : (f16)0.f;   // zero padding of the dwconv
+                    *(half8*)(dst + 16 * u) = o;
                 }
             }
-            __syncthreads();      // hp[j] visible to the consumers; they have finished with hp[j-1]
+        };
+
+        for (int j = 0; j <= NBH; ++j) {
+            if (j < NBH) {
+                f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+                float* dwl = dwbuf + (j & 1) * 576;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (tid + 256 * k < 576) dwl[tid + 256 * k] = dwreg[k];
+                if (j + 1 < NBH) load_dw(j + 1);
+                half_chunk(p_h, p_l, hp, j, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < NBH) load_frags(p_h, p_l, j + 1);          // x1 fragments of the next chunk
+                __builtin_amdgcn_sched_barrier(0);
+                half_chunk(q_h, q_l, hp, j, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < NBH) load_frags(q_h, q_l, NBH + j + 1);    // x2 fragments of the next chunk
+            }
+            __syncthreads();      // hp[j] / dw[j] visible to the consumers; they have finished with hp[j-1]
         }
         return;
     }

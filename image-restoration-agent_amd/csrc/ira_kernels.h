@@ -28,6 +28,11 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
                            float* attn_scratch, void* M, int T, int C, int heads, int S, int NB);
 
+// Fused attention front end (ira_qkv_fused.hip): LN + qkv 1x1 + depthwise 3x3 -> q,k (pixel-minor) and v (NHWC).
+bool qkv_fused_supported(int C);
+hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq,
+                            const float* dww, const float* dwb, void* qk, void* v, int T, int H, int W);
+
 // Fused GDFN (ira_ffn_fused.hip): x_out = x + ffn(LN(x)); x_out must not alias x.  Supported for C in {48, 96}.
 bool ffn_fused_supported(int C, int Hp);
 hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln_mode, int C, const void* Win,

@@ -1,0 +1,271 @@
+// Fused attention front end (restormer_arch.py:114 after :146's norm1), one kernel:
+//     qkv = dwconv3x3( conv1x1( LN(x) ) )            q,k -> fp16 pixel-minor [T][H][ceil(W/8)][2C][8], v -> fp16 NHWC
+// The 3C-channel pre-depthwise tensor never leaves the CU (it was written and re-read by two kernels before:
+// 2.1 KB/px -> 1.1 KB/px of HBM traffic at C = 96), at the price of recomputing the 1x1 on the 1-pixel halo.
+//
+// Same skeleton as ira_ffn_fused.hip: one workgroup = 8 waves per 8 x 32 output patch (10 x 34 halo = 11 groups of
+// 32 pixels); producers (waves 0-3) keep the LayerNorm-ed fp16 B-fragments of their halo groups in registers and
+// compute one 32-channel chunk of the 1x1 per step into an LDS double buffer, one chunk ahead, with the next
+// chunk's weight fragments prefetched; consumers (waves 4-7) run the depthwise 3x3 out of LDS with
+// v_fma_mix_f32 on 4-pixel x 8-channel register blocks (256 blocks per chunk = one per consumer lane) and
+// store q,k / v directly in the layouts the Gram and attention-apply kernels read.
+#include "ira_kernels.h"
+
+namespace ira {
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef f16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define IRA_DEV __device__ __forceinline__
+
+namespace {
+
+IRA_DEV long xcd_swz(long bid, long nblk) {
+    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+}
+
+IRA_DEV void fma_mix_lo(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+}
+IRA_DEV void fma_mix_hi(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+}
+IRA_DEV void dw_tap(float (&acc)[8], const u32x4 v, const f32x4 wl, const f32x4 wh) {
+    fma_mix_lo(acc[0], v[0], wl[0]); fma_mix_hi(acc[1], v[0], wl[1]);
+    fma_mix_lo(acc[2], v[1], wl[2]); fma_mix_hi(acc[3], v[1], wl[3]);
+    fma_mix_lo(acc[4], v[2], wh[0]); fma_mix_hi(acc[5], v[2], wh[1]);
+    fma_mix_lo(acc[6], v[3], wh[2]); fma_mix_hi(acc[7], v[3], wh[3]);
+}
+
+constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PHW = PH * PW;   // 340 halo pixels
+constexpr int NG1 = (PHW + 31) / 32;                                        // 11 pixel groups
+constexpr int HPS = 40;                                                     // row stride in halfs (32 + 8 pad): conflict-free
+constexpr int HP_ROWS = NG1 * 32;
+constexpr size_t HP_BYTES = (size_t)HP_ROWS * HPS * 2;                      // 28 160 B
+constexpr size_t DW_BYTES = 9 * 32 * 4;
+constexpr size_t QKV_LDS = 2 * HP_BYTES + 2 * DW_BYTES;                     // 58 624 B
+
+}  // namespace
+
+// BIN: the 1x1 has a bias (LayerNorm bias folded and/or conv bias); CB: depthwise bias present (cfg.bias).
+template <int C, int LN, bool BIN, bool CB>
+__global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, const f16* __restrict__ Wq,
+                                                   const float* __restrict__ bq, const float* __restrict__ dww,
+                                                   const float* __restrict__ dwb, f16* __restrict__ qk,
+                                                   f16* __restrict__ vout, int T, int H, int W) {
+    constexpr int KS = C / 16;
+    constexpr int NQ = 3 * C;                     // real qkv channels
+    constexpr int NCH = (NQ + 31) / 32;           // 32-channel chunks (the last one may be half padding)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* hpbuf = (f16*)smem;                                  // [2][HP_ROWS][HPS]
+    float* dwbuf = (float*)(smem + 2 * HP_BYTES);             // [2][9][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
+    const long pid = xcd_swz(blockIdx.x, gridDim.x);
+    const int t = (int)(pid / ((long)npy * npx));
+    const int py = (int)((pid / npx) % npy), pxx = (int)(pid % npx);
+    const int y0 = py * TH, x0 = pxx * TW;
+    const float* xt = x + (long)t * H * W * C;
+
+    if (wave < 4) {
+        // =========================== producers ===========================
+        constexpr int MAXG = 3;
+        half8 b[MAXG][KS];
+        bool inimg[MAXG];
+#pragma unroll
+        for (int gi = 0; gi < MAXG; ++gi) {
+            const int g = wave + 4 * gi;
+            const int q = 32 * g + r;
+            const int hy = q / PW, hx = q - hy * PW;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* src = xt + ((long)(inimg[gi] ? yy : 0) * W + (inimg[gi] ? xx : 0)) * C + 8 * h;
+            float xv[KS][8];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += xv[s][j];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+            const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[gi][s][j] = (f16)((xv[s][j] - sub) * rstd);
+        }
+        const long w_lo = (long)NCH * KS * 512;
+        const f16* wl_ = Wq + lane * 8;
+        const int ngroups = (wave + 8 < NG1) ? 3 : 2;
+
+        half8 f_h[KS], f_l[KS], n_h[KS], n_l[KS];     // this chunk's / the next chunk's weight fragments (hi, lo)
+        auto load_frags = [&](half8 (&fh)[KS], half8 (&fl)[KS], int nbrow) {
+            const f16* w = wl_ + (long)nbrow * KS * 512;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { fh[s] = *(const half8*)(w + s * 512); fl[s] = *(const half8*)(w + w_lo + s * 512); }
+        };
+        float dwreg[2];
+        auto load_dw = [&](int j) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + 256 * k;              // tid < 256: the four producer waves; 288 entries
+                const int tap = i >> 5, cc = i & 31;
+                const int ch = 32 * j + cc;
+                dwreg[k] = (i < 288 && ch < NQ) ? dww[(long)tap * NQ + ch] : 0.f;
+            }
+        };
+        load_frags(f_h, f_l, 0);
+        load_dw(0);
+
+        for (int j = 0; j <= NCH; ++j) {
+            if (j < NCH) {
+                f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+                float* dwl = dwbuf + (j & 1) * 288;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) if (tid + 256 * k < 288) dwl[tid + 256 * k] = dwreg[k];
+                if (j + 1 < NCH) { load_dw(j + 1); load_frags(n_h, n_l, j + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < MAXG; ++gi) {
+                    if (gi >= ngroups) break;
+                    f32x16 acc;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[8 * u + e] = BIN ? bq[32 * j + 16 * u + 8 * h + e] : 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_h[s], b[gi][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_l[s], b[gi][s], acc, 0, 0, 0);
+                    }
+                    const int q = 32 * (wave + 4 * gi) + r;
+                    f16* dst = hp + (long)q * HPS + 8 * h;
+                    const bool in = inimg[gi];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        half8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = in ? (f16)acc[8 * u + e] : (f16)0.f;   // zero padding of the dwconv
+                        *(half8*)(dst + 16 * u) = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { f_h[s] = n_h[s]; f_l[s] = n_l[s]; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // =========================== consumers ===========================
+    // lane -> (channel octet o of the chunk, 4-pixel block blk of the row, row of the patch)
+    const int o = lane & 3, blk = (lane >> 2) & 7, prow = 2 * (wave - 4) + (lane >> 5);
+    const int oy = y0 + prow, ox = x0 + 4 * blk;
+    const int WB = (W + 7) >> 3;
+    __syncthreads();                              // chunk 0 ready
+    for (int j = 0; j < NCH; ++j) {
+        const f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+        const float* dwl = dwbuf + (j & 1) * 288;
+        const int n0 = 32 * j + 8 * o;            // first qkv channel of this lane's octet
+        float acc[4][8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = (CB && n0 < NQ) ? dwb[n0 + e] : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            u32x4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = *(const u32x4*)(hp + (long)((prow + dy) * PW + 4 * blk + i) * HPS + 8 * o);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x4 wl = *(const f32x4*)(dwl + (dy * 3 + dx) * 32 + 8 * o);
+                const f32x4 wh = *(const f32x4*)(dwl + (dy * 3 + dx) * 32 + 8 * o + 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dw_tap(acc[p], v[p + dx], wl, wh);
+            }
+        }
+        // q,k rows are padded to WB*8 pixels and the padding must read as zero for the Gram: store every 4-pixel
+        // block below WB*8 (patches cover x < ceil(W/32)*32 >= WB*8), zeros for x >= W
+        if (oy < H && n0 < NQ && (n0 < 2 * C ? ox < WB * 8 : ox < W)) {
+            if (n0 < 2 * C) {
+                // q / k: pixel-minor, this lane owns 4 pixels (half of an 8-pixel vector) of 8 channels
+                f16* dst = qk + ((((long)(t * H + oy) * WB + (ox >> 3)) * (2 * C)) + n0) * 8 + (ox & 7);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    half4 q4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) q4[p] = (ox + p < W) ? (f16)acc[p][e] : (f16)0.f;
+                    *(half4*)(dst + e * 8) = q4;
+                }
+            } else {
+                f16* dst = vout + ((long)(t * H + oy) * W + ox) * C + (n0 - 2 * C);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (ox + p < W) {
+                        half8 o8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] = (f16)acc[p][e];
+                        *(half8*)(dst + (long)p * C) = o8;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool qkv_fused_supported(int C) { return C == 48 || C == 96; }
+
+template <int C, int LN, bool BIN, bool CB>
+static hipError_t qkv_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww,
+                              const float* dwb, f16* qk, f16* v, int T, int H, int W) {
+    const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    hipLaunchKernelGGL((k_qkv_fused<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(512), QKV_LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    return hipGetLastError();
+}
+
+template <int C>
+static hipError_t qkv_launch(hipStream_t st, const float* x, int ln_mode, const f16* Wq, const float* bq, const float* dww,
+                             const float* dwb, f16* qk, f16* v, int T, int H, int W) {
+#define IRA_QKV(LN_, BIN_, CB_) return qkv_launch2<C, LN_, BIN_, CB_>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W)
+    if (ln_mode == 1) {
+        if (bq) { if (dwb) IRA_QKV(1, true, true); else IRA_QKV(1, true, false); }
+        else { if (dwb) IRA_QKV(1, false, true); else IRA_QKV(1, false, false); }
+    } else {
+        if (bq) { if (dwb) IRA_QKV(2, true, true); else IRA_QKV(2, true, false); }
+        else { if (dwb) IRA_QKV(2, false, true); else IRA_QKV(2, false, false); }
+    }
+#undef IRA_QKV
+}
+
+hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq,
+                            const float* dww, const float* dwb, void* qk, void* v, int T, int H, int W) {
+    if ((ln_mode != 1 && ln_mode != 2) || !qkv_fused_supported(C)) return hipErrorInvalidValue;
+    // rows of the pixel-minor q,k tensor are padded to 8 pixels; the padding must read as zero for the Gram:
+    // patches cover x < ceil(W/32)*32 >= WB*8, and out-of-image pixels are stored as zeros above
+    if (C == 48) return qkv_launch<48>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+    return qkv_launch<96>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+}
+
+}  // namespace ira

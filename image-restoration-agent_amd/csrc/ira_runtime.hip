@@ -295,8 +295,14 @@ int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, 
     const int S = gram_splits(T, heads, nblk);
     hipStream_t st = m->st;
     // MDTA (:111-132)
-    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
-    RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
+    if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
+        char kq[64];
+        if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
+        RUN(m, kq, ira::launch_qkv_fused(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
+    } else {
+        RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
+        RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
+    }
     RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
     RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
     RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
@@ -732,6 +738,11 @@ int ira_op_conv3x3(ira_model_t* m, const float* in, const void* W, const float* 
 int ira_op_ffn_fused(ira_model_t* m, const float* x, float* xo, int ln_mode, int C, const void* Win, const float* bin,
                      const float* dww, const float* dwb, const void* Wout, const float* bout, int T, int H, int W, int Hp) {
     OP_BODY(m, "op", ira::launch_ffn_fused(m->st, x, xo, ln_mode, C, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp));
+}
+
+int ira_op_qkv_fused(ira_model_t* m, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                     const float* dwb, void* qk, void* v, int T, int H, int W) {
+    OP_BODY(m, "op", ira::launch_qkv_fused(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W));
 }
 
 int ira_set_fused_ffn(ira_model_t* m, int on) {

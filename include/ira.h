@@ -186,6 +186,14 @@ int ira_op_ffn_fused(ira_model_t* m, const float* x_dev, float* x_out_dev, int l
                      const void* Win_dev, const float* bin_dev, const float* dww_dev, const float* dwb_dev,
                      const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
 
+/* Fused attention front end: LN + qkv 1x1 + depthwise 3x3 (restormer_arch.py:105-106,114) in one kernel; C in {48, 96}.
+ * x fp32 NHWC (T,H,W,C); Wq packed qkv weights (LN gain folded, hi/lo, fragment-major), bq fp32 or NULL; dww fp32
+ * [9][3C], dwb [3C] or NULL; outputs as ira_op_dwconv_qkv: q,k pixel-minor (T,H,ceil(W/8),2C,8), v NHWC (T,H,W,C). */
+int ira_op_qkv_fused(ira_model_t* m, const float* x_dev, int ln_mode, int C, const void* Wq_dev, const float* bq_dev,
+                     const float* dww_dev, const float* dwb_dev, void* qk_dev, void* v_dev, int T, int H, int W);
+
+/* Switch the fused kernels (GDFN, attention front end) on (default) or off (per-op kernel path); for A/B measurements.
+ * (name kept from the first fused kernel) */
 /* Switch the fused GDFN kernel on (default) or off (three-kernel path); for A/B measurements. */
 int ira_set_fused_ffn(ira_model_t* m, int on);
 

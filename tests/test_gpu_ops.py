@@ -364,3 +364,55 @@ def test_ffn_fused(ctx, C, hid, ln, T, H, W, bias):
     err = (got - ref).abs().max().item()
     scale = (ref - x.permute(0, 2, 3, 1)).abs().max().item()
     assert err <= 4e-3 * scale + 1e-4, (err, scale)
+
+
+@pytest.mark.parametrize('C,ln,T,H,W,bias', [
+    (48, 1, 2, 11, 40, False),      # ragged patch edges; W % 8 == 0
+    (96, 1, 1, 16, 64, False),
+    (96, 2, 2, 9, 37, True),        # WithBias LN + biases; W % 8 = 5: zero-padded pixel-minor rows
+    (48, 2, 1, 8, 33, False),       # W % 8 = 1
+])
+def test_qkv_fused(ctx, C, ln, T, H, W, bias):
+    """LN + qkv 1x1 + depthwise 3x3 in one kernel (restormer_arch.py:105-106,114) against the fp32 torch ops."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    from oracle import restormer_oracle as O
+    g = torch.Generator().manual_seed(C + ln + W)
+    hid = 32
+    x = torch.randn(T, C, H, W, generator=g) * 1.5
+    sd = {
+        'b.norm1.body.weight': 1 + 0.1 * torch.randn(C, generator=g), 'b.norm2.body.weight': torch.ones(C),
+        'b.attn.temperature': torch.ones(1, 1, 1), 'b.attn.qkv.weight': torch.randn(3 * C, C, 1, 1, generator=g) / C ** 0.5,
+        'b.attn.qkv_dwconv.weight': torch.randn(3 * C, 1, 3, 3, generator=g) / 3,
+        'b.attn.project_out.weight': torch.zeros(C, C, 1, 1),
+        'b.ffn.project_in.weight': torch.zeros(2 * hid, C, 1, 1), 'b.ffn.dwconv.weight': torch.zeros(2 * hid, 1, 3, 3),
+        'b.ffn.project_out.weight': torch.zeros(C, hid, 1, 1),
+    }
+    if ln == 2:
+        sd['b.norm1.body.bias'] = 0.1 * torch.randn(C, generator=g)
+        sd['b.norm2.body.bias'] = torch.zeros(C)
+    if bias:
+        for k, n in [('attn.qkv', 3 * C), ('attn.qkv_dwconv', 3 * C), ('attn.project_out', C), ('ffn.project_in', 2 * hid),
+                     ('ffn.dwconv', 2 * hid), ('ffn.project_out', C)]:
+            sd[f'b.{k}.bias'] = 0.1 * torch.randn(n, generator=g)
+    ln_type = 'BiasFree' if ln == 1 else 'WithBias'
+    cfg = RestormerConfig(dim=C, LayerNorm_type=ln_type, bias=bias)
+    cfg.hidden = lambda d: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    xn = O.layer_norm(x, sd['b.norm1.body.weight'], sd.get('b.norm1.body.bias'), ln_type)
+    qkv = F.conv2d(F.conv2d(xn, sd['b.attn.qkv.weight'], sd.get('b.attn.qkv.bias')), sd['b.attn.qkv_dwconv.weight'],
+                   sd.get('b.attn.qkv_dwconv.bias'), padding=1, groups=3 * C)
+    q_ref = px_minor(qkv[:, :2 * C])
+    v_ref = qkv[:, 2 * C:].permute(0, 2, 3, 1).contiguous()
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v))) for k, v in arrs.items()}
+    xd = dev(x.permute(0, 2, 3, 1))
+    WB = (W + 7) // 8
+    qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
+    v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
+    rc = ctx._lib.ira_op_qkv_fused(ctx.handle, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
+                                   ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    # fp16 LN output and fp16 1x1 output inside: a few fp16 ulps of the intermediate magnitudes
+    close(v.cpu().float(), v_ref, 4e-3, 3e-3)
+    close(qk.cpu().float(), q_ref, 4e-3, 3e-3)
