@@ -290,6 +290,218 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-shared-weight variants for the wide levels (C = 192 / 384).  There a weight block is 24-48 KB and each
+// wave of k_pw_kres / k_pw_nres streamed the whole matrix (up to 3 MB) from L2 for its 32 pixels: the kernels were
+// L2-bandwidth bound at ~0.5 TB/s of useful traffic.  Here the 4 waves of a workgroup stage every weight block in
+// LDS cooperatively (each wave fetches a quarter, one block ahead, through registers) and all read it back with
+// conflict-free ds_read_b128: 4x less L2 traffic.  Waves never exit early (barriers): out-of-range waves clamp.
+template <int KS, int LN, bool IN_F32>
+__global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xin, const f16* __restrict__ W,
+                                                     const float* __restrict__ bias, f16* __restrict__ y,
+                                                     int y_stride, int n_store, int NB, int T, int P) {
+    constexpr int K = KS * 16;
+    constexpr int F = 2 * KS;                 // fragments (1 KB each) per 32-row weight block: hi plane then lo plane
+    constexpr int SH = F / 4;                 // fragments each wave stages per block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* wl = (half8*)smem;                 // [2][F][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int chunks = (P + 31) >> 5;
+    const long total = (long)T * chunks;
+    long wv = (long)blockIdx.x * 4 + wave;
+    const bool live = wv < total;
+    if (!live) wv = total - 1;
+    const int t = (int)(wv / chunks);
+    const int p = (int)(wv % chunks) * 32 + r;
+    const bool valid = live && p < P;
+    const long px = (long)t * P + (p < P ? p : P - 1);
+
+    half8 b[KS];
+    if constexpr (IN_F32) {
+        const float* src = (const float*)xin + px * K + 8 * h;
+        float sum = 0.f, sq = 0.f;
+        // two passes over registers would need K/2 fp32 registers per lane; for K = 384 that is 192: keep fp32
+        // only for the statistics (re-read from L1/L2 for the normalisation pass)
+        if constexpr (LN != 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += lo[j] + hi[j];
+            }
+            sum += __shfl_xor(sum, 32);
+        }
+        const float mu = sum * (1.0f / K);
+        if constexpr (LN != 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d0 = lo[j] - mu, d1 = hi[j] - mu; sq += d0 * d0 + d1 * d1; }
+            }
+            sq += __shfl_xor(sq, 32);
+        }
+        const float rstd = (LN != 0) ? 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f) : 1.0f;
+        const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[s][j] = (f16)((lo[j] - sub) * rstd); b[s][4 + j] = (f16)((hi[j] - sub) * rstd); }
+        }
+    } else {
+        const f16* src = (const f16*)xin + px * K + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = *(const half8*)(src + 16 * s);
+    }
+
+    // fragment f of block nb: f < KS -> hi plane k-step f, else lo plane k-step f-KS
+    auto gsrc = [&](int nb, int f) -> const half8* {
+        const long plane = (f < KS) ? 0 : (long)NB * KS * 512;
+        return (const half8*)(W + plane + ((long)nb * KS + (f < KS ? f : f - KS)) * 512 + lane * 8);
+    };
+    half8 stg[SH];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) stg[i] = *gsrc(0, wave + 4 * i);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) wl[(wave + 4 * i) * 64 + lane] = stg[i];
+    __syncthreads();
+
+    for (int nb = 0; nb < NB; ++nb) {
+        const half8* cur = wl + (nb & 1) * F * 64;
+        if (nb + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < SH; ++i) stg[i] = *gsrc(nb + 1, wave + 4 * i);     // prefetch, issued before the stores below
+        }
+        f32x16 acc;
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[8 * u + j] = bias[32 * nb + 16 * u + 8 * h + j];
+        } else {
+            acc = zero16();
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s * 64 + lane], b[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(KS + s) * 64 + lane], b[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * nb + 16 * u + 8 * h;
+            if (valid && n0 + 8 <= n_store) {
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)acc[8 * u + j];
+                *(half8*)(y + px * y_stride + n0) = o;
+            }
+        }
+        if (nb + 1 < NB) {
+            half8* nxt = wl + ((nb + 1) & 1) * F * 64;
+#pragma unroll
+            for (int i = 0; i < SH; ++i) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NB, bool IN_F32>
+__global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0, int K0, const void* __restrict__ x1, int K1,
+                                                     const f16* __restrict__ W, long w_tile_stride,
+                                                     const float* __restrict__ bias, const float* resid, float* y,
+                                                     int N, int T, int P) {
+    // one weight "slab" = all NB row blocks of ONE k-step, hi and lo planes: F = 2*NB fragments of 1 KB.
+    // Per-tile weights (attention apply): all four waves of a workgroup must be in the same tile, so the wave ->
+    // pixel map is per tile: chunks4 = ceil(chunks / 4) workgroups per tile.
+    constexpr int F = 2 * NB;
+    constexpr int SH = (F + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* wl = (half8*)smem;                 // [2][F][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int chunks = (P + 31) >> 5;
+    const int wg_per_tile = (chunks + 3) >> 2;
+    const int t = blockIdx.x / wg_per_tile;
+    const int ch = (blockIdx.x % wg_per_tile) * 4 + wave;
+    const bool live = ch < chunks;
+    const int p = (live ? ch : chunks - 1) * 32 + r;
+    const bool valid = live && p < P;
+    const long px = (long)t * P + (p < P ? p : P - 1);
+    const int K = K0 + K1, KT = K >> 4;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        acc[nb] = zero16();
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * nb + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        }
+    }
+    const f16* wt = W + (long)t * w_tile_stride + lane * 8;
+    const long lo_off = (long)NB * KT * 512;
+    auto gsrc = [&](int s, int f) -> const half8* {     // f < NB: hi plane block f, else lo plane block f-NB
+        return (const half8*)(wt + (f < NB ? 0 : lo_off) + ((long)(f < NB ? f : f - NB) * KT + s) * 512);
+    };
+    half8 stg[SH];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(0, wave + 4 * i);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[(wave + 4 * i) * 64 + lane] = stg[i];
+    __syncthreads();
+
+    for (int s = 0; s < KT; ++s) {
+        const half8* cur = wl + (s & 1) * F * 64;
+        if (s + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(s + 1, wave + 4 * i);
+        }
+        const int c0 = 16 * s;
+        half8 b;
+        if constexpr (IN_F32) {
+            const float* src = (c0 < K0) ? ((const float*)x0 + px * K0 + c0 + 8 * h) : ((const float*)x1 + px * K1 + (c0 - K0) + 8 * h);
+            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else {
+            const f16* src = (c0 < K0) ? ((const f16*)x0 + px * K0 + c0 + 8 * h) : ((const f16*)x1 + px * K1 + (c0 - K0) + 8 * h);
+            b = *(const half8*)src;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[nb * 64 + lane], b, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(NB + nb) * 64 + lane], b, acc[nb], 0, 0, 0);
+        }
+        if (s + 1 < KT) {
+            half8* nxt = wl + ((s + 1) & 1) * F * 64;
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * nb + 16 * u + 8 * h;
+            if (n0 + 8 <= N) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
+                if (resid != nullptr) {
+                    lo += *(const f32x4*)(resid + px * N + n0);
+                    hi += *(const f32x4*)(resid + px * N + n0 + 4);
+                }
+                *(f32x4*)(y + px * N + n0) = lo;
+                *(f32x4*)(y + px * N + n0 + 4) = hi;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Depthwise 3x3, zero padding (restormer_arch.py:84,106).  One thread = 8 consecutive pixels of one
 // image row x 8 channels (an 8x8 register block): 3 rows x 10 input vectors (16 B each) per block.
 //   in: fp16 NHWC [T][H][W][Cs];  w: fp32 [9][Cs] (tap-major), bias fp32 [Cs] or null.
@@ -826,8 +1038,32 @@ static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int
 }
 
 template <int KS>
+static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
+                                     f16* y, int ys, int ns, int NB, int T, int P) {
+    const long waves = (long)T * ((P + 31) / 32);
+    const dim3 grid(grid1d(waves, 4)), block(256);
+    const size_t smem = (size_t)2 * 2 * KS * 1024;
+#define IRA_KL(LN_, F32_)                                                                                               \
+    do {                                                                                                                \
+        static bool done_ = false;                                                                                      \
+        if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
+        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P);      \
+    } while (0)
+    if (in_f32) {
+        if (ln == 0) IRA_KL(0, true); else if (ln == 1) IRA_KL(1, true); else IRA_KL(2, true);
+    } else {
+        if (ln != 0) return hipErrorInvalidValue;
+        IRA_KL(0, false);
+    }
+#undef IRA_KL
+    return hipGetLastError();
+}
+
+template <int KS>
 static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
                                    const float* bias, f16* y, int ys, int ns, int NB, int T, int P) {
+    static const int lds_env = env_int("IRA_PW_LDS", 1);
+    if constexpr (KS >= 12) { if (lds_env) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
     static const int pg_env = env_int("IRA_KRES_PG", 0);
     int pg = pg_env > 0 ? pg_env : (KS <= 4 ? 4 : (KS <= 12 ? 2 : 1));
     while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;        // tiny tiles: do not pad a wave with empty groups
@@ -860,9 +1096,23 @@ static hipError_t pw_nres_launch(hipStream_t st, const void* x0, int K0, const v
 }
 
 template <int NB>
+static hipError_t pw_nres_lds_launch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
+                                     const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
+                                     int T, int P) {
+    const int chunks = (P + 31) / 32;
+    const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4))), block(256);
+    const size_t smem = (size_t)2 * 2 * NB * 1024;
+    if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    else hipLaunchKernelGGL((k_pw_nres_lds<NB, false>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    return hipGetLastError();
+}
+
+template <int NB>
 static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                    const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                    int T, int P) {
+    static const int lds_env = env_int("IRA_PW_LDS", 1);
+    if constexpr (NB >= 6) { if (lds_env) return pw_nres_lds_launch<NB>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
     static const int pg_env = env_int("IRA_NRES_PG", 0);
     int pg = pg_env > 0 ? pg_env : (NB <= 4 ? 2 : 1);
     while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;
