@@ -49,6 +49,8 @@ def family_elements(family, C, Hf):
         'ln_pin_1x1': C + 2 * Hf,     # G4
         'dwconv_gate': 3 * Hf,        # G5: read 2Hf, write Hf
         'pout_res': Hf + 2 * C,       # G6
+        'qkv_fused': 8 * C,           # G1 + G2 in one kernel
+        'ffn_fused': 3 * C + 6 * Hf,  # G4 + G5 + G6 in one kernel (its real HBM traffic is ~2.3C: see DESIGN.md)
     }.get(family, 0)
 
 

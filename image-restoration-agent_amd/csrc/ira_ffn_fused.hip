@@ -78,6 +78,13 @@ constexpr size_t FFN_LDS = 2 * HP_BYTES + 2 * DW_BYTES;                     // d
 
 // BIN: project_in has a bias (LayerNorm bias folded and/or conv bias); CB: depthwise / project_out biases present
 // (cfg.bias, never set by the reference tasks).  Compile-time so that the hot loops carry no per-element branches.
+#ifdef IRA_FFN_STAMPS
+__device__ unsigned long long g_ffn_stamps[2][64];     // [producer wave 0 / consumer wave 4][event]
+#define STAMP(role, idx) do { if (blockIdx.x == 777 && lane == 0 && (wave == 0 || wave == 4)) g_ffn_stamps[role][idx] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(role, idx) do {} while (0)
+#endif
+
 template <int C, int LN, bool BIN, bool CB>
 __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, float* __restrict__ xo,
                                                    const f16* __restrict__ Win, const float* __restrict__ bin,
@@ -99,46 +106,53 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
     const float* xt = x + (long)t * H * W * C;
     const int NBH = Hp >> 5;              // 32-channel chunks of x1 (= of x2)
 
+    STAMP(wave == 0 ? 0 : 1, 0);
+    // ---- prologue, all 8 waves: LayerNorm of the halo patch -> fp16 MFMA B-fragments, staged through LDS (the
+    // region is reused by the hp buffers afterwards).  One HBM round trip for the whole workgroup instead of three
+    // sequential ones in the producer waves while the consumers idle (measured with s_memtime: 19k -> ~8k cycles).
+    half8* xnl = (half8*)smem;                    // [NG1][KS][64], 66 KB at C = 96 (the hp buffers are 101 KB)
+    for (int g = wave; g < NG1; g += 8) {
+        const int q = 32 * g + r;
+        const int hy = q / PW, hx = q - hy * PW;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* src = xt + ((long)(in ? yy : 0) * W + (in ? xx : 0)) * C + 8 * h;
+        float xv[KS][8];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += xv[s][j];
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+        const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((xv[s][j] - sub) * rstd);
+            xnl[(g * KS + s) * 64 + lane] = o;
+        }
+    }
+
     if (wave < 4) {
         // =========================== producers ===========================
         constexpr int MAXG = 3;
         half8 b[MAXG][KS];
         bool inimg[MAXG];
-#pragma unroll
-        for (int gi = 0; gi < MAXG; ++gi) {
-            const int g = wave + 4 * gi;
-            const int q = 32 * g + r;
-            const int hy = q / PW, hx = q - hy * PW;
-            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float* src = xt + ((long)(inimg[gi] ? yy : 0) * W + (inimg[gi] ? xx : 0)) * C + 8 * h;
-            float xv[KS][8];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum += xv[s][j];
-            sum += __shfl_xor(sum, 32);
-            const float mu = sum * (1.0f / C);
-            float sq = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
-            const float sub = (LN == 2) ? mu : 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[gi][s][j] = (f16)((xv[s][j] - sub) * rstd);
-        }
         const long win_lo = (long)(2 * NBH) * KS * 512;
         const f16* winl = Win + lane * 8;
         const int ngroups = (wave + 8 < NG1) ? 3 : 2;
@@ -162,9 +176,22 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
                 dwreg[k] = (i < 576) ? dww[(long)tap * 2 * Hp + ch] : 0.f;
             }
         };
-        load_frags(p_h, p_l, 0);
+        load_frags(p_h, p_l, 0);                  // requested before the barrier: their L2 latency hides behind it
         load_frags(q_h, q_l, NBH);
         load_dw(0);
+        __syncthreads();                          // (A) every group's B-fragments are in LDS
+#pragma unroll
+        for (int gi = 0; gi < MAXG; ++gi) {
+            const int g = wave + 4 * gi;
+            const int q = 32 * g + r;
+            const int hy = q / PW, hx = q - hy * PW;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[gi][s] = xnl[((g < NG1 ? g : 0) * KS + s) * 64 + lane];
+        }
+        __syncthreads();                          // (B) fragments are in registers: the LDS region becomes the hp buffers
+        STAMP(0, 1);
 
         auto half_chunk = [&](const half8 (&fh)[KS], const half8 (&fl)[KS], f16* hp, int j, int xsel) {
 #pragma unroll
@@ -208,7 +235,9 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
                 __builtin_amdgcn_sched_barrier(0);
                 if (j + 1 < NBH) load_frags(q_h, q_l, NBH + j + 1);    // x2 fragments of the next chunk
             }
+            STAMP(0, 2 + 2 * j);
             __syncthreads();      // hp[j] / dw[j] visible to the consumers; they have finished with hp[j-1]
+            STAMP(0, 3 + 2 * j);
         }
         return;
     }
@@ -224,7 +253,11 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) { accA[nb][e] = 0.f; accB[nb][e] = 0.f; }
 
+    __syncthreads();                              // (A)
+    __syncthreads();                              // (B)
+    STAMP(1, 1);
     __syncthreads();                              // hp[0], dw[0] ready
+    STAMP(1, 2);
     for (int j = 0; j < NBH; ++j) {
         const f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
         const float* dwl = dwbuf + (j & 1) * 576;
@@ -281,10 +314,26 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
                 accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol[nb], fB, accB[nb], 0, 0, 0);
             }
         }
+        STAMP(1, 3 + 2 * j);
         __syncthreads();          // done with hp[j] / dw[j]; hp[j+1] / dw[j+1] are ready
+        STAMP(1, 4 + 2 * j);
     }
 
-    // ---- epilogue: x_out = x + acc (+ bias), fp32
+    // ---- epilogue: x_out = x + acc (+ bias), fp32.  All residual loads are issued before the first use.
+    f32x4 xr[2][NBC][2][2];
+#pragma unroll
+    for (int rowsel = 0; rowsel < 2; ++rowsel) {
+        const int oyy = min(y0 + 2 * cw + rowsel, H - 1), oxx = min(x0 + r, W - 1);
+        const long po = ((long)t * H + oyy) * W + oxx;
+#pragma unroll
+        for (int nb = 0; nb < NBC; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = min(32 * nb + 16 * u + 8 * h, C - 8);
+                xr[rowsel][nb][u][0] = *(const f32x4*)(x + po * C + n0);
+                xr[rowsel][nb][u][1] = *(const f32x4*)(x + po * C + n0 + 4);
+            }
+    }
 #pragma unroll
     for (int rowsel = 0; rowsel < 2; ++rowsel) {
         const int oyy = y0 + 2 * cw + rowsel, oxx = x0 + r;
@@ -296,7 +345,7 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
             for (int u = 0; u < 2; ++u) {
                 const int n0 = 32 * nb + 16 * u + 8 * h;
                 if (n0 + 8 <= C) {
-                    f32x4 lo = *(const f32x4*)(x + po * C + n0), hi = *(const f32x4*)(x + po * C + n0 + 4);
+                    f32x4 lo = xr[rowsel][nb][u][0], hi = xr[rowsel][nb][u][1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v0 = rowsel ? accB[nb][8 * u + e] : accA[nb][8 * u + e];
@@ -309,7 +358,14 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
                 }
             }
     }
+    STAMP(1, 30);
 }
+
+#ifdef IRA_FFN_STAMPS
+extern "C" int ira_debug_ffn_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffn_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 bool ffn_fused_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0; }
 

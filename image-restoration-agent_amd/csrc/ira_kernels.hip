@@ -1111,8 +1111,8 @@ template <int NB>
 static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                    const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                    int T, int P) {
-    static const int lds_env = env_int("IRA_PW_LDS", 1);
-    if constexpr (NB >= 6) { if (lds_env) return pw_nres_lds_launch<NB>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
+    static const int lds_env = env_int("IRA_PW_LDS", 2);
+    if (lds_env >= 2 || (NB >= 6 && lds_env)) return pw_nres_lds_launch<NB>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P);
     static const int pg_env = env_int("IRA_NRES_PG", 0);
     int pg = pg_env > 0 ? pg_env : (NB <= 4 ? 2 : 1);
     while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;

@@ -66,6 +66,16 @@ def main():
         gbs = (rd + wb) / avg if f and w else float('nan')
         out.append(f'| {key[0]} | {key[1]} | {n} | {avg / 1e3:.1f} | {100 * sum(durs) / total:.1f} | {rd / 1e6:.1f} | {wb / 1e6:.1f} | {gbs:.0f} |')
         traffic[f'{key[0]}|grid{key[1]}'] = {'calls': n, 'avg_us': avg / 1e3, 'hbm_read_bytes': rd, 'hbm_write_bytes': wb}
+    # traffic of the two fused kernels under the keys bench.py uses (profile run = bench defaults: T = 40, tile 512)
+    import re as _re
+    for key in list(tr.keys()):
+        m_ = _re.match(r'k_(ffn|qkv)_fused<(\d+)', key[0]) or _re.match(r'_ZN3ira11k_(ffn|qkv)_fusedILi(\d+)', key[0])
+        if m_ and key in fe and key in wr:
+            patches = key[1] // 512
+            for T_, side in ((40, 512), (40, 256), (8, 512), (8, 256)):
+                if patches == T_ * ((side + 7) // 8) * ((side + 31) // 32):
+                    traffic[f'{m_.group(1)}_fused|C{m_.group(2)}|{side}x{side}|T{T_}'] = int(2.0 * 1024 * sum(fe[key]) / len(fe[key]) + 1024.0 * sum(wr[key]) / len(wr[key]))
+                    break
     text = f'total kernel time {total / 1e6:.2f} ms over {sum(len(v) for v in tr.values())} dispatches\n\n' + '\n'.join(out) + '\n'
     if len(sys.argv) > 2:
         open(sys.argv[2], 'w').write(text)

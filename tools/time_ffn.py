@@ -29,3 +29,11 @@ t0 = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize()
 print('IRA_FFN_DBG=%s C=%d: %.3f ms' % (os.environ.get('IRA_FFN_DBG', '0'), Cc, (time.perf_counter() - t0) * 100))
+if os.environ.get('IRA_HIP_LIB', '').endswith('stamps.so'):
+    buf = (C.c_ulonglong * 128)()
+    lib = C.CDLL(os.environ['IRA_HIP_LIB'])
+    assert lib.ira_debug_ffn_stamps(buf) == 0
+    prod = [buf[i] for i in range(64)]; cons = [buf[64 + i] for i in range(64)]
+    t0 = min(prod[0], cons[0])
+    print('producer stamps (cycles@100MHz? raw delta):', [int(v - t0) for v in prod[:20]])
+    print('consumer stamps:', [int(v - t0) for v in cons[:20]], 'end', int(cons[30] - t0))
