@@ -48,7 +48,8 @@ constexpr int HPS = 40;                                                     // r
 constexpr int HP_ROWS = NG1 * 32;
 constexpr size_t HP_BYTES = (size_t)HP_ROWS * HPS * 2;                      // 28 160 B
 constexpr size_t DW_BYTES = 9 * 32 * 4;
-constexpr size_t QKV_LDS = 2 * HP_BYTES + 2 * DW_BYTES;                     // 58 624 B
+constexpr size_t QKV_LDS_MAIN = 2 * HP_BYTES + 2 * DW_BYTES;                // 58 624 B
+constexpr size_t QKV_LDS = (QKV_LDS_MAIN > (size_t)NG1 * 6 * 1024 ? QKV_LDS_MAIN : (size_t)NG1 * 6 * 1024) + 1024;   // >= 66 KB prologue staging (C = 96)
 
 }  // namespace
 
@@ -73,46 +74,51 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
     const int y0 = py * TH, x0 = pxx * TW;
     const float* xt = x + (long)t * H * W * C;
 
+    // ---- prologue, all 8 waves: LayerNorm of the halo patch -> fp16 B-fragments staged in LDS (region reused by the
+    // hp buffers afterwards): one HBM round trip for the workgroup instead of three sequential ones in the producers.
+    half8* xnl = (half8*)smem;                    // [NG1][KS][64]: 66 KB at C = 96 (needs QKV_LDS >= that)
+    for (int g = wave; g < NG1; g += 8) {
+        const int q = 32 * g + r;
+        const int hy = q / PW, hx = q - hy * PW;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* src = xt + ((long)(in ? yy : 0) * W + (in ? xx : 0)) * C + 8 * h;
+        float xv[KS][8];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += xv[s][j];
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+        const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((xv[s][j] - sub) * rstd);
+            xnl[(g * KS + s) * 64 + lane] = o;
+        }
+    }
+
     if (wave < 4) {
         // =========================== producers ===========================
         constexpr int MAXG = 3;
         half8 b[MAXG][KS];
         bool inimg[MAXG];
-#pragma unroll
-        for (int gi = 0; gi < MAXG; ++gi) {
-            const int g = wave + 4 * gi;
-            const int q = 32 * g + r;
-            const int hy = q / PW, hx = q - hy * PW;
-            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float* src = xt + ((long)(inimg[gi] ? yy : 0) * W + (inimg[gi] ? xx : 0)) * C + 8 * h;
-            float xv[KS][8];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum += xv[s][j];
-            sum += __shfl_xor(sum, 32);
-            const float mu = sum * (1.0f / C);
-            float sq = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
-            sq += __shfl_xor(sq, 32);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
-            const float sub = (LN == 2) ? mu : 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[gi][s][j] = (f16)((xv[s][j] - sub) * rstd);
-        }
         const long w_lo = (long)NCH * KS * 512;
         const f16* wl_ = Wq + lane * 8;
         const int ngroups = (wave + 8 < NG1) ? 3 : 2;
@@ -133,46 +139,62 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
                 dwreg[k] = (i < 288 && ch < NQ) ? dww[(long)tap * NQ + ch] : 0.f;
             }
         };
-        load_frags(f_h, f_l, 0);
+        load_frags(f_h, f_l, 0);                  // requested before the barrier: their latency hides behind it
         load_dw(0);
+        __syncthreads();                          // (A) every group's B-fragments are in LDS
+#pragma unroll
+        for (int gi = 0; gi < MAXG; ++gi) {
+            const int g = wave + 4 * gi;
+            const int q = 32 * g + r;
+            const int hy = q / PW, hx = q - hy * PW;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            inimg[gi] = (g < NG1) && (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[gi][s] = xnl[((g < NG1 ? g : 0) * KS + s) * 64 + lane];
+        }
+        __syncthreads();                          // (B) fragments are in registers: the LDS region becomes the hp buffers
 
-        for (int j = 0; j <= NCH; ++j) {
-            if (j < NCH) {
-                f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
-                float* dwl = dwbuf + (j & 1) * 288;
+        // chunk j computes from (ch, cl) while the fragments of chunk j+1 stream into (nh, nl): the two register sets
+        // ping-pong (loop unrolled by two, no copies), so a prefetch has a whole chunk period to land
+        auto do_chunk = [&](int j, const half8 (&ch)[KS], const half8 (&cl)[KS], half8 (&nh)[KS], half8 (&nl)[KS]) {
+            f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
+            float* dwl = dwbuf + (j & 1) * 288;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) if (tid + 256 * k < 288) dwl[tid + 256 * k] = dwreg[k];
-                if (j + 1 < NCH) { load_dw(j + 1); load_frags(n_h, n_l, j + 1); }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 2; ++k) if (tid + 256 * k < 288) dwl[tid + 256 * k] = dwreg[k];
+            if (j + 1 < NCH) { load_dw(j + 1); load_frags(nh, nl, j + 1); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int gi = 0; gi < MAXG; ++gi) {
-                    if (gi >= ngroups) break;
-                    f32x16 acc;
+            for (int gi = 0; gi < MAXG; ++gi) {
+                if (gi >= ngroups) break;
+                f32x16 acc;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[8 * u + e] = BIN ? bq[32 * j + 16 * u + 8 * h + e] : 0.f;
+                    for (int e = 0; e < 8; ++e) acc[8 * u + e] = BIN ? bq[32 * j + 16 * u + 8 * h + e] : 0.f;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_h[s], b[gi][s], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f_l[s], b[gi][s], acc, 0, 0, 0);
-                    }
-                    const int q = 32 * (wave + 4 * gi) + r;
-                    f16* dst = hp + (long)q * HPS + 8 * h;
-                    const bool in = inimg[gi];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        half8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = in ? (f16)acc[8 * u + e] : (f16)0.f;   // zero padding of the dwconv
-                        *(half8*)(dst + 16 * u) = o;
-                    }
+                for (int s = 0; s < KS; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], b[gi][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[s], b[gi][s], acc, 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                const int q = 32 * (wave + 4 * gi) + r;
+                f16* dst = hp + (long)q * HPS + 8 * h;
+                const bool in = inimg[gi];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) { f_h[s] = n_h[s]; f_l[s] = n_l[s]; }
+                for (int u = 0; u < 2; ++u) {
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = in ? (f16)acc[8 * u + e] : (f16)0.f;   // zero padding of the dwconv
+                    *(half8*)(dst + 16 * u) = o;
+                }
             }
+        };
+        for (int j = 0; j <= NCH; j += 2) {
+            if (j < NCH) do_chunk(j, f_h, f_l, n_h, n_l);
             __syncthreads();
+            if (j + 1 <= NCH) {
+                if (j + 1 < NCH) do_chunk(j + 1, n_h, n_l, f_h, f_l);
+                __syncthreads();
+            }
         }
         return;
     }
@@ -182,6 +204,8 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
     const int o = lane & 3, blk = (lane >> 2) & 7, prow = 2 * (wave - 4) + (lane >> 5);
     const int oy = y0 + prow, ox = x0 + 4 * blk;
     const int WB = (W + 7) >> 3;
+    __syncthreads();                              // (A)
+    __syncthreads();                              // (B)
     __syncthreads();                              // chunk 0 ready
     for (int j = 0; j < NCH; ++j) {
         const f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
@@ -241,6 +265,12 @@ template <int C, int LN, bool BIN, bool CB>
 static hipError_t qkv_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww,
                               const float* dwb, f16* qk, f16* v, int T, int H, int W) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_fused<C, LN, BIN, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QKV_LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     hipLaunchKernelGGL((k_qkv_fused<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(512), QKV_LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
     return hipGetLastError();
 }
