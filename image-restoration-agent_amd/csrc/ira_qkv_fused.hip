@@ -24,6 +24,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also waits vmcnt(0): every chunk would then wait for the
+// consumers' global STORES to be acknowledged and would drain the producers' weight prefetches (measured with
+// s_memtime: 4.1k cycles per chunk for ~350 VALU instructions).  The LDS traffic only needs lgkmcnt(0) + s_barrier.
+IRA_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 IRA_DEV long xcd_swz(long bid, long nblk) {
     const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
@@ -36,6 +45,14 @@ IRA_DEV void fma_mix_hi(float& acc, unsigned packed, float w) {
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
 }
 IRA_DEV void dw_tap(float (&acc)[8], const u32x4 v, const f32x4 wl, const f32x4 wh) {
+#ifdef IRA_NO_FMA_MIX
+    const half8 hv = *(const half8*)&v;
+    acc[0] = fmaf((float)hv[0], wl[0], acc[0]); acc[1] = fmaf((float)hv[1], wl[1], acc[1]);
+    acc[2] = fmaf((float)hv[2], wl[2], acc[2]); acc[3] = fmaf((float)hv[3], wl[3], acc[3]);
+    acc[4] = fmaf((float)hv[4], wh[0], acc[4]); acc[5] = fmaf((float)hv[5], wh[1], acc[5]);
+    acc[6] = fmaf((float)hv[6], wh[2], acc[6]); acc[7] = fmaf((float)hv[7], wh[3], acc[7]);
+    return;
+#endif
     fma_mix_lo(acc[0], v[0], wl[0]); fma_mix_hi(acc[1], v[0], wl[1]);
     fma_mix_lo(acc[2], v[1], wl[2]); fma_mix_hi(acc[3], v[1], wl[3]);
     fma_mix_lo(acc[4], v[2], wh[0]); fma_mix_hi(acc[5], v[2], wh[1]);
@@ -77,40 +94,54 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
     // ---- prologue, all 8 waves: LayerNorm of the halo patch -> fp16 B-fragments staged in LDS (region reused by the
     // hp buffers afterwards): one HBM round trip for the workgroup instead of three sequential ones in the producers.
     half8* xnl = (half8*)smem;                    // [NG1][KS][64]: 66 KB at C = 96 (needs QKV_LDS >= that)
-    for (int g = wave; g < NG1; g += 8) {
-        const int q = 32 * g + r;
-        const int hy = q / PW, hx = q - hy * PW;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float* src = xt + ((long)(in ? yy : 0) * W + (in ? xx : 0)) * C + 8 * h;
-        float xv[KS][8];
+    {
+        // a wave owns halo groups `wave` and `wave + 8` (the second only for waves 0-2): the loads of BOTH are issued
+        // before either LayerNorm, so the prologue costs one HBM round trip, not two
+        constexpr int NPG = 2;
+        float xv[NPG][KS][8];
+        bool have[NPG];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+        for (int gi = 0; gi < NPG; ++gi) {
+            const int g = wave + 8 * gi;
+            have[gi] = g < NG1;
+            const int q = 32 * (have[gi] ? g : 0) + r;
+            const int hy = q / PW, hx = q - hy * PW;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool in = (q < PHW) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* src = xt + ((long)(in ? yy : 0) * W + (in ? xx : 0)) * C + 8 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { xv[s][j] = lo[j]; xv[s][4 + j] = hi[j]; }
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = *(const f32x4*)(src + 16 * s), hi = *(const f32x4*)(src + 16 * s + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[gi][s][j] = lo[j]; xv[gi][s][4 + j] = hi[j]; }
+            }
         }
-        float sum = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int gi = 0; gi < NPG; ++gi) {
+            float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += xv[s][j];
-        sum += __shfl_xor(sum, 32);
-        const float mu = sum * (1.0f / C);
-        float sq = 0.f;
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+                for (int j = 0; j < 8; ++j) sum += xv[gi][s][j];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / C);
+            float sq = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
-        const float sub = (LN == 2) ? mu : 0.f;
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            half8 o;
+                for (int j = 0; j < 8; ++j) { const float d = xv[gi][s][j] - mu; sq += d * d; }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+            const float sub = (LN == 2) ? mu : 0.f;
+            if (have[gi]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)((xv[s][j] - sub) * rstd);
-            xnl[(g * KS + s) * 64 + lane] = o;
+                for (int s = 0; s < KS; ++s) {
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)((xv[gi][s][j] - sub) * rstd);
+                    xnl[((wave + 8 * gi) * KS + s) * 64 + lane] = o;
+                }
+            }
         }
     }
 
@@ -134,14 +165,16 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int i = tid + 256 * k;              // tid < 256: the four producer waves; 288 entries
-                const int tap = i >> 5, cc = i & 31;
+                const int ii = (i < 288) ? i : 287;
+                const int tap = ii >> 5, cc = ii & 31;
                 const int ch = 32 * j + cc;
-                dwreg[k] = (i < 288 && ch < NQ) ? dww[(long)tap * NQ + ch] : 0.f;
+                const float wv = dww[(long)tap * NQ + (ch < NQ ? ch : NQ - 1)];      // unconditional load, clamped address
+                dwreg[k] = (ch < NQ) ? wv : 0.f;
             }
         };
         load_frags(f_h, f_l, 0);                  // requested before the barrier: their latency hides behind it
         load_dw(0);
-        __syncthreads();                          // (A) every group's B-fragments are in LDS
+        lds_barrier();                          // (A) every group's B-fragments are in LDS
 #pragma unroll
         for (int gi = 0; gi < MAXG; ++gi) {
             const int g = wave + 4 * gi;
@@ -152,7 +185,7 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
 #pragma unroll
             for (int s = 0; s < KS; ++s) b[gi][s] = xnl[((g < NG1 ? g : 0) * KS + s) * 64 + lane];
         }
-        __syncthreads();                          // (B) fragments are in registers: the LDS region becomes the hp buffers
+        lds_barrier();                          // (B) fragments are in registers: the LDS region becomes the hp buffers
 
         // chunk j computes from (ch, cl) while the fragments of chunk j+1 stream into (nh, nl): the two register sets
         // ping-pong (loop unrolled by two, no copies), so a prefetch has a whole chunk period to land
@@ -190,10 +223,10 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
         };
         for (int j = 0; j <= NCH; j += 2) {
             if (j < NCH) do_chunk(j, f_h, f_l, n_h, n_l);
-            __syncthreads();
+            lds_barrier();
             if (j + 1 <= NCH) {
                 if (j + 1 < NCH) do_chunk(j + 1, n_h, n_l, f_h, f_l);
-                __syncthreads();
+                lds_barrier();
             }
         }
         return;
@@ -204,9 +237,9 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
     const int o = lane & 3, blk = (lane >> 2) & 7, prow = 2 * (wave - 4) + (lane >> 5);
     const int oy = y0 + prow, ox = x0 + 4 * blk;
     const int WB = (W + 7) >> 3;
-    __syncthreads();                              // (A)
-    __syncthreads();                              // (B)
-    __syncthreads();                              // chunk 0 ready
+    lds_barrier();                              // (A)
+    lds_barrier();                              // (B)
+    lds_barrier();                              // chunk 0 ready
     for (int j = 0; j < NCH; ++j) {
         const f16* hp = hpbuf + (size_t)(j & 1) * HP_ROWS * HPS;
         const float* dwl = dwbuf + (j & 1) * 288;
@@ -216,19 +249,26 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[p][e] = (CB && n0 < NQ) ? dwb[n0 + e] : 0.f;
+        // all 36 LDS reads of the chunk are issued before the first FMA: with one consumer wave per SIMD nothing else
+        // hides LDS latency (18 exposed round trips per chunk otherwise: 4.1k -> cycles per chunk measured)
+        u32x4 v[3][6];
+        f32x4 wl[9], wh[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            u32x4 v[6];
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = *(const u32x4*)(hp + (long)((prow + dy) * PW + 4 * blk + i) * HPS + 8 * o);
+            for (int i = 0; i < 6; ++i) v[dy][i] = *(const u32x4*)(hp + (long)((prow + dy) * PW + 4 * blk + i) * HPS + 8 * o);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const f32x4 wl = *(const f32x4*)(dwl + (dy * 3 + dx) * 32 + 8 * o);
-                const f32x4 wh = *(const f32x4*)(dwl + (dy * 3 + dx) * 32 + 8 * o + 4);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) dw_tap(acc[p], v[p + dx], wl, wh);
-            }
+        for (int tap = 0; tap < 9; ++tap) {
+            wl[tap] = *(const f32x4*)(dwl + tap * 32 + 8 * o);
+            wh[tap] = *(const f32x4*)(dwl + tap * 32 + 8 * o + 4);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dw_tap(acc[p], v[dy][p + dx], wl[dy * 3 + dx], wh[dy * 3 + dx]);
         // q,k rows are padded to WB*8 pixels and the padding must read as zero for the Gram: store every 4-pixel
         // block below WB*8 (patches cover x < ceil(W/32)*32 >= WB*8), zeros for x >= W
         if (oy < H && n0 < NQ && (n0 < 2 * C ? ox < WB * 8 : ox < W)) {
@@ -255,7 +295,7 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
