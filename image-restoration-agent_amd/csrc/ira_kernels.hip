@@ -874,6 +874,118 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
             }
 }
 
+// LDS-shared-weight variant of k_conv3x3 for the wide convs (Upsample 384->768 etc.): per (tap, k-step) the
+// 4 waves of a workgroup stage the slab of NBW row blocks x {hi, lo} fragments in LDS once (one step ahead) instead of
+// each wave streaming the whole 9*K*N weight tensor (up to 10 MB per 32 pixels) from L2.
+template <int NBW, int MODE>
+__global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ in, const f16* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ skip,
+                                                     float* __restrict__ out, int T, int H, int Wd, int K, int N,
+                                                     int NBtot) {
+    constexpr int F = 2 * NBW;
+    constexpr int SH = (F + 3) / 4;
+    __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int P = H * Wd;
+    const int chunks = (P + 31) >> 5;
+    const long total = (long)T * chunks;
+    long wv = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;
+    const bool live = wv < total;
+    if (!live) wv = total - 1;
+    const int nb0 = blockIdx.y * NBW;
+    const int t = (int)(wv / chunks);
+    const int p = (int)(wv % chunks) * 32 + r;
+    const bool valid = live && p < P;
+    const int pc = (p < P) ? p : P - 1;
+    const int y = pc / Wd, x = pc % Wd;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        acc[nb] = zero16();
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        }
+    }
+    const int KT = K >> 4;
+    const int nsteps = 9 * KT;
+    const long lo_off = 9L * NBtot * KT * 512;
+    // fragment f of step (tap, s): f < NBW -> hi plane, row block nb0+f; else lo plane, row block nb0+f-NBW
+    auto gsrc = [&](int step, int f) -> const half8* {
+        const int tap = step / KT, s = step - tap * KT;
+        int nb = nb0 + (f < NBW ? f : f - NBW);
+        if (nb >= NBtot) nb = NBtot - 1;                      // partial last chunk: staged but never used
+        return (const half8*)(W + (f < NBW ? 0 : lo_off) + (((long)tap * NBtot + nb) * KT + s) * 512 + lane * 8);
+    };
+    half8 stg[SH];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(0, wave + 4 * i);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[0][wave + 4 * i][lane] = stg[i];
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int tap = step / KT, s = step - tap * KT;
+        if (step + 1 < nsteps) {
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(step + 1, wave + 4 * i);
+        }
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+        const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h + 16 * s;
+        f32x4 lo4 = *(const f32x4*)src, hi4 = *(const f32x4*)(src + 4);
+        if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
+        const half8 b = cvt8(lo4, hi4);
+        half8 bl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bl[j] = (f16)(lo4[j] - (float)b[j]); bl[4 + j] = (f16)(hi4[j] - (float)b[4 + j]); }
+        const int cur = step & 1;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            if (nb0 + nb < NBtot) {
+                const half8 a = wl[cur][nb][lane], al = wl[cur][NBW + nb][lane];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+            }
+        }
+        if (step + 1 < nsteps) {
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[cur ^ 1][wave + 4 * i][lane] = stg[i];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                if (n >= N) continue;
+                const float val = acc[nb][8 * u + j];
+                if constexpr (MODE == 0) {
+                    out[((long)t * P + p) * N + n] = val;
+                } else if constexpr (MODE == 1) {
+                    const int oc = n * 4 + (y & 1) * 2 + (x & 1);
+                    out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
+                } else if constexpr (MODE == 2) {
+                    const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                } else {
+                    const long o = ((long)t * P + p) * N + n;
+                    out[o] = val + skip[o];
+                }
+            }
+}
+
 // ---------------------------------------------------------------------------------------------
 // OverlapPatchEmbed (restormer_arch.py:156-165): 3x3 conv from 1/3 input channels, fp32 VALU (exact
 // fp32 like the reference; 0.1% of the FLOPs).  One thread = one pixel x 8 output channels.
@@ -1185,6 +1297,15 @@ static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W
     const long waves = (long)T * (((long)H * Wd + 31) / 32);
     const int NBW = NB >= 6 ? 6 : (NB >= 3 ? 3 : (NB == 2 ? 2 : 1));
     const dim3 grid(grid1d(waves, 4), (NB + NBW - 1) / NBW), block(256);
+    static const int lds_env = env_int("IRA_CONV_LDS", 1);
+    if (lds_env && NB >= 2) {      // every multi-block conv: weights through LDS
+        switch (NBW) {
+            case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+            case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+            default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+        }
+        return hipGetLastError();
+    }
     switch (NBW) {
         case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
         case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
