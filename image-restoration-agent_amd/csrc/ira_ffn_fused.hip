@@ -22,6 +22,8 @@
 // (g) values, weights as fp16 hi+lo planes, fp32 accumulation / LN statistics / dwconv / GELU.
 #include "ira_kernels.h"
 
+#include <cstdlib>
+
 namespace ira {
 
 typedef _Float16 f16;
@@ -427,6 +429,9 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* xo, int ln_mo
                             const float* dww, const float* dwb, const void* Wout, const float* bout, int T, int H, int W,
                             int Hp) {
     if (x == xo || (ln_mode != 1 && ln_mode != 2) || !ffn_fused_supported(C, Hp)) return hipErrorInvalidValue;
+    // 12-wave experiment (ira_ffn_fused12.hip): ties at C = 48, spills and loses 7 % at C = 96 -> opt-in only
+    static const int use12 = getenv("IRA_FFN12") ? atoi(getenv("IRA_FFN12")) : 0;
+    if (use12) return launch_ffn_fused12(st, x, xo, ln_mode, C, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
     if (C == 48) return ffn_launch<48>(st, x, xo, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
     return ffn_launch<96>(st, x, xo, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
 }

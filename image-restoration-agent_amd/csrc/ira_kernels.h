@@ -39,6 +39,11 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln
                             const float* bin, const float* dww, const float* dwb, const void* Wout, const float* bout,
                             int T, int H, int W, int Hp);
 
+// 12-wave variant (ira_ffn_fused12.hip): one producer + two consumer waves per SIMD.
+hipError_t launch_ffn_fused12(hipStream_t st, const float* x, float* x_out, int ln_mode, int C, const void* Win,
+                              const float* bin, const float* dww, const float* dwb, const void* Wout, const float* bout,
+                              int T, int H, int W, int Hp);
+
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);
 
