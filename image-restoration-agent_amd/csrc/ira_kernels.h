@@ -10,7 +10,7 @@ namespace ira {
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K,
                           const void* W, const float* bias, void* y, int y_stride, int n_store,
-                          int NB, int T, int P);
+                          int NB, int T, int P, float eps = 1e-5f);
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                           const void* W, long w_tile_stride, const float* bias, const float* resid,
@@ -62,5 +62,16 @@ hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c,
 
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
 hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
+
+// ---- NAFNet (ira_nafnet.hip).  inmode: 0 fp16, 1 fp16 SimpleGate pair, 2 fp32 space-to-depth (2x2 stride-2 conv), 3 fp32;
+// outmode: 0 plain (+resid), 1 PixelShuffle(2) + add resid at the destination.  (Hg, Wg) = the MFMA pixel grid.
+hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
+                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg);
+int naf_dw_sg_blocks(int H, int W, int c);      // partial-sum records per image written by launch_naf_dw_sg
+hipError_t launch_naf_dw_sg(hipStream_t st, const void* in, const float* w, const float* bias, void* out, float* part,
+                            int T, int H, int W, int c);
+hipError_t launch_naf_sca_fold(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca,
+                               const float* w3, const float* beta, float* s, void* M, int T, int c, int NB);
+hipError_t launch_naf_pad_crop(hipStream_t st, const float* in, float* out, int T, int Hi, int Wi, int Ho, int Wo, int C);
 
 }  // namespace ira

@@ -86,7 +86,7 @@ IRA_DEV float gelu_erf(float x) {
 template <int KS, int LN, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, f16* __restrict__ y,
-                                                 int y_stride, int n_store, int NB, int T, int P) {
+                                                 int y_stride, int n_store, int NB, int T, int P, float eps) {
     constexpr int K = KS * 16;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int chunks = (P + 32 * PG - 1) / (32 * PG);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
                 sq += __shfl_xor(sq, 32);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + eps);
                 const float sub = (LN == 2) ? mu : 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
 template <int KS, int LN, bool IN_F32>
 __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xin, const f16* __restrict__ W,
                                                      const float* __restrict__ bias, f16* __restrict__ y,
-                                                     int y_stride, int n_store, int NB, int T, int P) {
+                                                     int y_stride, int n_store, int NB, int T, int P, float eps) {
     constexpr int K = KS * 16;
     constexpr int F = 2 * KS;                 // fragments (1 KB each) per 32-row weight block: hi plane then lo plane
     constexpr int SH = F / 4;                 // fragments each wave stages per block
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
             }
             sq += __shfl_xor(sq, 32);
         }
-        const float rstd = (LN != 0) ? 1.0f / sqrtf(sq * (1.0f / K) + 1e-5f) : 1.0f;
+        const float rstd = (LN != 0) ? 1.0f / sqrtf(sq * (1.0f / K) + eps) : 1.0f;
         const float sub = (LN == 2) ? mu : 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -1135,10 +1135,10 @@ static int env_int(const char* name, int dflt) {
 
 template <int KS, int PG>
 static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
-                                 f16* y, int ys, int ns, int NB, int T, int P) {
+                                 f16* y, int ys, int ns, int NB, int T, int P, float eps) {
     const long waves = (long)T * ((P + 32 * PG - 1) / (32 * PG));
     const dim3 grid(grid1d(waves, 4)), block(256);
-#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_, PG>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P)
+#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_, PG>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P, eps)
     if (in_f32) {
         if (ln == 0) IRA_KRES(0, true); else if (ln == 1) IRA_KRES(1, true); else IRA_KRES(2, true);
     } else {
@@ -1151,7 +1151,7 @@ static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int
 
 template <int KS>
 static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
-                                     f16* y, int ys, int ns, int NB, int T, int P) {
+                                     f16* y, int ys, int ns, int NB, int T, int P, float eps) {
     const long waves = (long)T * ((P + 31) / 32);
     const dim3 grid(grid1d(waves, 4)), block(256);
     const size_t smem = (size_t)2 * 2 * KS * 1024;
@@ -1159,7 +1159,7 @@ static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32,
     do {                                                                                                                \
         static bool done_ = false;                                                                                      \
         if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
-        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P);      \
+        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps);      \
     } while (0)
     if (in_f32) {
         if (ln == 0) IRA_KL(0, true); else if (ln == 1) IRA_KL(1, true); else IRA_KL(2, true);
@@ -1173,24 +1173,27 @@ static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32,
 
 template <int KS>
 static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
-                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P) {
+                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P, float eps) {
     static const int lds_env = env_int("IRA_PW_LDS", 1);
-    if constexpr (KS >= 12) { if (lds_env) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
+    if constexpr (KS >= 16) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps);
+    else {
+    if constexpr (KS >= 12) { if (lds_env) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
     static const int pg_env = env_int("IRA_KRES_PG", 0);
     int pg = pg_env > 0 ? pg_env : (KS <= 4 ? 4 : (KS <= 12 ? 2 : 1));
     while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;        // tiny tiles: do not pad a wave with empty groups
-    if constexpr (KS <= 6) { if (pg >= 4) return pw_kres_launch<KS, 4>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
-    if constexpr (KS <= 12) { if (pg >= 2) return pw_kres_launch<KS, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P); }
-    return pw_kres_launch<KS, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P);
+    if constexpr (KS <= 6) { if (pg >= 4) return pw_kres_launch<KS, 4>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
+    if constexpr (KS <= 12) { if (pg >= 2) return pw_kres_launch<KS, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
+    return pw_kres_launch<KS, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps);
+    }
 }
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
-                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P) {
+                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps) {
     if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
     const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
     switch (K / 16) {
-#define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P);
-        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(8) IRA_CASE(12) IRA_CASE(24)
+#define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P, eps);
+        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(8) IRA_CASE(12) IRA_CASE(16) IRA_CASE(24) IRA_CASE(32)
 #undef IRA_CASE
         default: return hipErrorInvalidValue;
     }

@@ -1,0 +1,410 @@
+// gfx950 kernels specific to NAFNet (reference X-Restormer/xrestormer/archs/NAFNet_arch.py:158-326).
+// Everything GEMM-shaped reuses the conventions of ira_kernels.hip (weights = MFMA A operand, fragment-major hi/lo
+// fp16 planes; 32 pixels = B operand; fp32 accumulators; fp32 NHWC residual stream, fp16 branch activations).
+//
+// One NAFBlock (:198-219) is scheduled as
+//   t1 = conv1(LN(x))                       k_pw_kres / k_pw_kres_lds  (LN gain/bias folded into W1, eps 1e-6)
+//   g  = SimpleGate(dw3x3(t1)), sum_px g    k_naf_dw_sg                 (per-workgroup partial channel sums)
+//   s  = sca(mean g)                        k_naf_sca                   (AdaptiveAvgPool2d(1) + 1x1, per image)
+//   M  = diag(beta) W3 diag(s)              k_naf_fold                  (the channel attention x*s and the beta scale
+//                                                                        become a per-image matrix, hi/lo planes)
+//   x += M g + beta*b3                      k_naf_pw<.., IN_F16, OUT_RES>
+//   t1 = conv4(LN(x))                       k_pw_kres
+//   x += (diag(gamma) W5)(t1a * t1b) + ..   k_naf_pw<.., IN_GATED, OUT_RES>   (SimpleGate applied while loading B)
+// and the U-Net plumbing: downs (2x2 stride-2 conv, :275-277) = k_naf_pw<.., IN_S2D, OUT_PLAIN> (K = 4c gathered from
+// the four source pixels), ups (1x1 c->2c + PixelShuffle(2), :286-291) plus the skip add (:320) =
+// k_naf_pw<.., IN_F32, OUT_SHUFFLE_ADD> (weight rows permuted by the packer so that 8 consecutive rows are 8
+// consecutive channels of ONE sub-pixel).
+#include "ira_kernels.h"
+
+namespace ira {
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IRA_DEV __device__ __forceinline__
+
+namespace {
+
+IRA_DEV long xcd_swz(long bid, long nblk) {
+    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+}
+IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
+IRA_DEV half8 cvt8(const f32x4 lo, const f32x4 hi) {
+    half8 o;
+    o[0] = (f16)lo[0]; o[1] = (f16)lo[1]; o[2] = (f16)lo[2]; o[3] = (f16)lo[3];
+    o[4] = (f16)hi[0]; o[5] = (f16)hi[1]; o[6] = (f16)hi[2]; o[7] = (f16)hi[3];
+    return o;
+}
+IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; return z; }
+IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
+IRA_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3 };
+enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// N-resident pointwise contraction with LDS-shared weight slabs (the skeleton of k_pw_nres_lds) and NAFNet's
+// operand forms.  MFMA pixel grid: T images of Hg x Wg pixels; one wave = 32 pixels, one workgroup = 128 pixels of
+// one image (per-image weights for the channel-attention fold).  blockIdx.y selects NBW of the NBtot 32-row blocks.
+//   IN_F16    x: fp16 [T][P][K]
+//   IN_GATED  x: fp16 [T][P][2K], B = x[.., k] * x[.., K + k]                       (SimpleGate :158-161)
+//   IN_S2D    x: fp32 [T][2Hg][2Wg][K/4], k = (dy*2+dx)*(K/4) + ci                  (2x2 stride-2 conv)
+//   IN_F32    x: fp32 [T][P][K]
+//   OUT_RES          y fp32 [T][P][N] = acc (+ resid)
+//   OUT_SHUFFLE_ADD  y fp32 [T][2Hg][2Wg][N/4]: row n = q*(N/4) + cc -> sub-pixel q = 2sy+sx, channel cc; + resid there
+template <int NBW, int INMODE, int OUTMODE>
+__global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, int K, const f16* __restrict__ W,
+                                                long w_tile_stride, const float* __restrict__ bias, const float* resid,
+                                                float* y, int N, int NBtot, int T, int Hg, int Wg) {
+    constexpr int F = 2 * NBW;
+    constexpr int SH = (F + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* wl = (half8*)smem;                 // [2][F][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int P = Hg * Wg;
+    const int chunks = (P + 31) >> 5;
+    const int wg_per_tile = (chunks + 3) >> 2;
+    const int t = blockIdx.x / wg_per_tile;
+    const int ch = (blockIdx.x % wg_per_tile) * 4 + wave;
+    const bool live = ch < chunks;
+    int p = (live ? ch : chunks - 1) * 32 + r;
+    const bool valid = live && p < P;
+    if (p >= P) p = P - 1;
+    const long px = (long)t * P + p;
+    const int KT = K >> 4;
+    const int nb0 = blockIdx.y * NBW;
+    const int Y = p / Wg, X = p - Y * Wg;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        acc[nb] = zero16();
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        }
+    }
+    const f16* wt = W + (long)t * w_tile_stride + lane * 8;
+    const long lo_off = (long)NBtot * KT * 512;
+    auto gsrc = [&](int s, int f) -> const half8* {     // f < NBW: hi plane block nb0+f, else lo plane block nb0+f-NBW
+        return (const half8*)(wt + (f < NBW ? 0 : lo_off) + ((long)(nb0 + (f < NBW ? f : f - NBW)) * KT + s) * 512);
+    };
+    half8 stg[SH];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(0, wave + 4 * i);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[(wave + 4 * i) * 64 + lane] = stg[i];
+    __syncthreads();
+
+    const int cs = K >> 2;                    // IN_S2D: source channels
+    const int spt = (KT >> 2) > 0 ? (KT >> 2) : 1;   // IN_S2D: k-steps per tap
+    for (int s = 0; s < KT; ++s) {
+        const half8* cur = wl + (s & 1) * F * 64;
+        if (s + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(s + 1, wave + 4 * i);
+        }
+        const int c0 = 16 * s + 8 * h;
+        half8 b;
+        if constexpr (INMODE == IN_F16) {
+            b = *(const half8*)((const f16*)xin + px * K + c0);
+        } else if constexpr (INMODE == IN_GATED) {
+            const f16* src = (const f16*)xin + px * 2 * K + c0;
+            const half8 a1 = *(const half8*)src, a2 = *(const half8*)(src + K);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (f16)((float)a1[j] * (float)a2[j]);
+        } else if constexpr (INMODE == IN_S2D) {
+            const int tap = s / spt, ci0 = (s - tap * spt) * 16 + 8 * h;
+            const float* src = (const float*)xin + (((long)t * 2 * Hg + 2 * Y + (tap >> 1)) * (2 * Wg) + 2 * X + (tap & 1)) * cs + ci0;
+            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else {
+            const float* src = (const float*)xin + px * K + c0;
+            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[nb * 64 + lane], b, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(NBW + nb) * 64 + lane], b, acc[nb], 0, 0, 0);
+        }
+        if (s + 1 < KT) {
+            half8* nxt = wl + ((s + 1) & 1) * F * 64;
+#pragma unroll
+            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    const int Nq = N >> 2;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * (nb0 + nb) + 16 * u + 8 * h;
+            if (n0 + 8 <= N) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
+                long dst;
+                if constexpr (OUTMODE == OUT_RES) {
+                    dst = px * N + n0;
+                } else {
+                    const int q = n0 / Nq, cc = n0 - q * Nq;
+                    dst = (((long)t * 2 * Hg + 2 * Y + (q >> 1)) * (2 * Wg) + 2 * X + (q & 1)) * Nq + cc;
+                }
+                if (resid != nullptr) {
+                    lo += *(const f32x4*)(resid + dst);
+                    hi += *(const f32x4*)(resid + dst + 4);
+                }
+                *(f32x4*)(y + dst) = lo;
+                *(f32x4*)(y + dst + 4) = hi;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv2 (depthwise 3x3 on 2c channels, zero padding, bias) + SimpleGate + per-workgroup partial sums of the gated
+// tensor for the channel attention's global average pool (:202-205).  One thread = 4 pixels x 8 gated channels.
+//   in fp16 [T][H][W][2c];  w fp32 [9][2c];  out fp16 [T][H][W][c];  part fp32 [T][bpt][c]
+// The grid is per image (bpt workgroups each) and the partials are reduced in a fixed order by k_naf_sca, so an
+// image's result does not depend on its batch.
+constexpr int NDW_PX = 4;
+
+template <int PX>
+IRA_DEV void naf_dw_block(const f16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, int H,
+                          int W, int Cs, int t, int y, int x0, int ch0, float (&acc)[PX][8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float bv = bias ? bias[ch0 + e] : 0.f;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[p][e] = bv;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= H) continue;
+        const f16* rowp = in + ((long)(t * H + yy) * W) * Cs + ch0;
+        half8 v[PX + 2];
+#pragma unroll
+        for (int i = 0; i < PX + 2; ++i) {
+            const int xx = x0 - 1 + i;
+            v[i] = (xx >= 0 && xx < W) ? *(const half8*)(rowp + (long)xx * Cs) : zero8();
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
+            const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
+            const float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[p + dx][e], wv[e], acc[p][e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_naf_dw_sg(const f16* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, f16* __restrict__ out,
+                                                   float* __restrict__ part, int T, int H, int W, int c, int bpt) {
+    __shared__ float sm[256][9];              // +1: conflict-free column reads
+    const int XB = (W + NDW_PX - 1) / NDW_PX, G = c >> 3;
+    const long bid = xcd_swz(blockIdx.x, gridDim.x);
+    const int t = (int)(bid / bpt), blk = (int)(bid % bpt);
+    const int tid = threadIdx.x;
+    const long idx = (long)blk * 256 + tid;
+    const long per_tile = (long)H * XB * G;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (idx < per_tile) {
+        const int g = (int)(idx % G);
+        const long rest = idx / G;
+        const int xq = (int)(rest % XB), y = (int)(rest / XB);
+        const int x0 = xq * NDW_PX;
+        float a1[NDW_PX][8], a2[NDW_PX][8];
+        naf_dw_block<NDW_PX>(in, w, bias, H, W, 2 * c, t, y, x0, g * 8, a1);
+        naf_dw_block<NDW_PX>(in, w, bias, H, W, 2 * c, t, y, x0, c + g * 8, a2);
+        f16* dst = out + ((long)(t * H + y) * W + x0) * c + g * 8;
+#pragma unroll
+        for (int p = 0; p < NDW_PX; ++p) {
+            if (x0 + p < W) {
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float gv = a1[p][e] * a2[p][e]; s[e] += gv; o[e] = (f16)gv; }
+                *(half8*)(dst + (long)p * c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[tid][e] = s[e];
+    __syncthreads();
+    // G divides 256 (c is a power of two <= 2048): threads tid, tid+G, ... hold the same channel group
+    for (int j = tid; j < c; j += 256) {
+        const int gi = j >> 3, e = j & 7;
+        float a = 0.f;
+        for (int k = gi; k < 256; k += G) a += sm[k][e];
+        part[((long)t * bpt + blk) * c + j] = a;
+    }
+}
+
+// s[t][o] = sca_b[o] + sum_k sca_w[o][k] * mean_px g[t][.., k]   (:175-179, :205).  grid (T, ceil(c/64)).
+__global__ __launch_bounds__(256) void k_naf_sca(const float* __restrict__ part, int bpt, float inv_px,
+                                                 const float* __restrict__ wsca, const float* __restrict__ bsca,
+                                                 float* __restrict__ s, int c) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // mean[c] + slices[256]
+    float* mean = lds;
+    float* sl = lds + c;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pb = part + (long)t * bpt * c;
+    if (c >= 256) {
+        for (int j = tid; j < c; j += 256) {
+            float a = 0.f;
+            for (int b = 0; b < bpt; ++b) a += pb[(long)b * c + j];
+            mean[j] = a * inv_px;
+        }
+    } else {
+        const int nsl = 256 / c, j = tid % c, sli = tid / c;    // c divides 256
+        float a = 0.f;
+        for (int b = sli; b < bpt; b += nsl) a += pb[(long)b * c + j];
+        sl[tid] = a;
+        __syncthreads();
+        if (tid < c) {
+            float m = 0.f;
+            for (int k = 0; k < nsl; ++k) m += sl[k * c + tid];
+            mean[tid] = m * inv_px;
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        const int o = blockIdx.y * 64 + wave * 16 + i;
+        if (o >= c) break;
+        float a = 0.f;
+        for (int k = lane; k < c; k += 64) a = fmaf(wsca[(long)o * c + k], mean[k], a);
+        a = wave_sum(a);
+        if (lane == 0) s[(long)t * c + o] = a + bsca[o];
+    }
+}
+
+// M[t] = diag(beta) W3 diag(s[t]) as fragment-major hi/lo fp16 planes [T][2][NB][c/16][64][8].  grid (T, ceil(c/16)).
+__global__ __launch_bounds__(256) void k_naf_fold(const float* __restrict__ s, const float* __restrict__ w3,
+                                                  const float* __restrict__ beta, f16* __restrict__ M, int c, int NB) {
+    const int t = blockIdx.x, o0 = blockIdx.y * 16, tid = threadIdx.x;
+    const int KT = c >> 4;
+    f16* Mt = M + (long)t * 2 * NB * KT * 512;
+    f16* Ml = Mt + (long)NB * KT * 512;
+    const float* st = s + (long)t * c;
+    for (int idx = tid; idx < 16 * c; idx += 256) {
+        const int o = o0 + idx / c, k = idx % c;
+        if (o >= c) continue;
+        const float a = beta[o] * w3[(long)o * c + k] * st[k];
+        const long off = (((long)(o >> 5) * KT + (k >> 4)) * 64 + 32 * ((k >> 3) & 1) + rowperm(o & 31)) * 8 + (k & 7);
+        const f16 hi = (f16)a;
+        Mt[off] = hi;
+        Ml[off] = (f16)(a - (float)hi);
+    }
+}
+
+// check_image_size (:356-361): zero pad to the right/bottom; and the final crop (:326).  fp32 NHWC, C channels.
+__global__ __launch_bounds__(256) void k_naf_pad_crop(const float* __restrict__ in, float* __restrict__ out, int T,
+                                                      int Hi, int Wi, int Ho, int Wo, int C) {
+    const long total = (long)T * Ho * Wo * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % C);
+        long rest = idx / C;
+        const int x = (int)(rest % Wo); rest /= Wo;
+        const int y = (int)(rest % Ho);
+        const int t = (int)(rest / Ho);
+        out[idx] = (y < Hi && x < Wi) ? in[(((long)t * Hi + y) * Wi + x) * C + ch] : 0.f;
+    }
+}
+
+// =============================================================================================
+template <int NBW, int INMODE, int OUTMODE>
+static hipError_t naf_pw_launch(hipStream_t st, const void* x, int K, const f16* W, long wts, const float* bias,
+                                const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+    const int chunks = (Hg * Wg + 31) / 32;
+    const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4)), (unsigned)(NBtot / NBW)), block(256);
+    const size_t smem = (size_t)2 * 2 * NBW * 1024;
+    hipLaunchKernelGGL((k_naf_pw<NBW, INMODE, OUTMODE>), grid, block, smem, st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+    return hipGetLastError();
+}
+
+template <int INMODE, int OUTMODE>
+static hipError_t naf_pw_nbw(hipStream_t st, const void* x, int K, const f16* W, long wts, const float* bias,
+                             const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+    if (NBtot % 8 == 0) return naf_pw_launch<8, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+    if (NBtot % 4 == 0) return naf_pw_launch<4, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+    if (NBtot % 2 == 0) return naf_pw_launch<2, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+    return naf_pw_launch<1, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+}
+
+hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
+                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+    if (K <= 0 || K % 16 != 0 || N % 8 != 0 || NBtot * 32 < N || T <= 0 || Hg <= 0 || Wg <= 0) return hipErrorInvalidValue;
+    if (inmode == IN_S2D && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
+    if (outmode == OUT_SHUFFLE_ADD && (N % 32 != 0)) return hipErrorInvalidValue;  // N/4 channels, runs of 8
+    const f16* Wh = (const f16*)W;
+#define IRA_NAF(IM, OM) return naf_pw_nbw<IM, OM>(st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg)
+    if (outmode == OUT_RES) {
+        switch (inmode) {
+            case IN_F16: IRA_NAF(IN_F16, OUT_RES);
+            case IN_GATED: IRA_NAF(IN_GATED, OUT_RES);
+            case IN_S2D: IRA_NAF(IN_S2D, OUT_RES);
+            case IN_F32: IRA_NAF(IN_F32, OUT_RES);
+            default: return hipErrorInvalidValue;
+        }
+    } else if (outmode == OUT_SHUFFLE_ADD && inmode == IN_F32) {
+        IRA_NAF(IN_F32, OUT_SHUFFLE_ADD);
+    }
+#undef IRA_NAF
+    return hipErrorInvalidValue;
+}
+
+int naf_dw_sg_blocks(int H, int W, int c) {
+    const long per_tile = (long)H * ((W + NDW_PX - 1) / NDW_PX) * (c / 8);
+    return (int)((per_tile + 255) / 256);
+}
+
+hipError_t launch_naf_dw_sg(hipStream_t st, const void* in, const float* w, const float* bias, void* out, float* part,
+                            int T, int H, int W, int c) {
+    if (c < 16 || (c & (c - 1)) != 0 || c > 2048) return hipErrorInvalidValue;
+    const int bpt = naf_dw_sg_blocks(H, W, c);
+    hipLaunchKernelGGL(k_naf_dw_sg, dim3((unsigned)((long)T * bpt)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out, part,
+                       T, H, W, c, bpt);
+    return hipGetLastError();
+}
+
+hipError_t launch_naf_sca_fold(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca,
+                               const float* w3, const float* beta, float* s, void* M, int T, int c, int NB) {
+    if (c < 16 || (c & (c - 1)) != 0 || c > 2048 || NB * 32 < c) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_naf_sca, dim3(T, (c + 63) / 64), dim3(256), (size_t)(c + 256) * sizeof(float), st, part, bpt,
+                       1.0f / (float)npx, wsca, bsca, s, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_naf_fold, dim3(T, (c + 15) / 16), dim3(256), 0, st, s, w3, beta, (f16*)M, c, NB);
+    return hipGetLastError();
+}
+
+hipError_t launch_naf_pad_crop(hipStream_t st, const float* in, float* out, int T, int Hi, int Wi, int Ho, int Wo, int C) {
+    long g = ((long)T * Ho * Wo * C + 255) / 256;
+    if (g > 65536) g = 65536;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_naf_pad_crop, dim3((unsigned)g), dim3(256), 0, st, in, out, T, Hi, Wi, Ho, Wo, C);
+    return hipGetLastError();
+}
+
+}  // namespace ira

@@ -30,11 +30,31 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
 
 struct Prof { long launches = 0; double ms = 0; };
 
+struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into the weight blob
+    const void* c1_w = nullptr;  const float* c1_b = nullptr;     // conv1 with norm1 folded in
+    const float* dw_w = nullptr; const float* dw_b = nullptr;     // conv2 (depthwise 3x3)
+    const float* sca_w = nullptr; const float* sca_b = nullptr;   // sca.1
+    const float* c3_w = nullptr; const float* beta = nullptr; const float* c3_b = nullptr;   // conv3 fp32 (folded per image), beta*b3
+    const void* c4_w = nullptr;  const float* c4_b = nullptr;     // conv4 with norm2 folded in
+    const void* c5_w = nullptr;  const float* c5_b = nullptr;     // diag(gamma) conv5, gamma*b5
+};
+
 }  // namespace
 
 struct ira_model {
     int device = -1;
+    int arch = 0;                    // 0 Restormer, 1 NAFNet
     ira_restormer_config cfg{};
+    ira_nafnet_config ncfg{};
+    // NAFNet weights / workspace
+    std::vector<std::vector<NBlk>> nenc, ndec;
+    std::vector<NBlk> nmid;
+    const float *intro_w = nullptr, *intro_b = nullptr, *ending_b = nullptr;
+    const void* ending_w = nullptr;
+    std::vector<const void*> ndown_w, nup_w;
+    std::vector<const float*> ndown_b;
+    std::vector<float*> nx;          // residual stream per level (encoder output = skip, reused by the decoder)
+    float *npad_in = nullptr, *npad_out = nullptr, *nsca = nullptr;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
     std::mutex mu;
@@ -329,7 +349,7 @@ int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt,
 }
 
 // ---- Restormer.forward (restormer_arch.py:245-284) on device NHWC fp32, T tiles of H x W (enqueue only)
-int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
     const ira_restormer_config& c = m->cfg;
     if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
         return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);
@@ -363,6 +383,167 @@ int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* o
     if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
     RUN(m, "conv3x3_out", ira::launch_conv3x3(st, d1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
     return IRA_OK;
+}
+
+
+// =============================================================================================
+// NAFNet (NAFNet_arch.py:249-361): weights, workspace, forward schedule
+int naf_levels(const ira_nafnet_config& c) { return c.n_levels; }
+
+bool naf_load_block(ira_model* m, const std::string& p, int c, NBlk& b) {
+    const size_t NBc = up32(c), NB2 = up32(2 * c);
+    m->err.clear();
+    b.c1_w = wptr(m, p + ".c1_w", true, 2 * NB2 * c * 2);
+    b.c1_b = (const float*)wptr(m, p + ".c1_b", true, NB2 * 4);
+    b.dw_w = (const float*)wptr(m, p + ".dw_w", true, (size_t)9 * 2 * c * 4);
+    b.dw_b = (const float*)wptr(m, p + ".dw_b", true, (size_t)2 * c * 4);
+    b.sca_w = (const float*)wptr(m, p + ".sca_w", true, (size_t)c * c * 4);
+    b.sca_b = (const float*)wptr(m, p + ".sca_b", true, (size_t)c * 4);
+    b.c3_w = (const float*)wptr(m, p + ".c3_w", true, (size_t)c * c * 4);
+    b.beta = (const float*)wptr(m, p + ".beta", true, (size_t)c * 4);
+    b.c3_b = (const float*)wptr(m, p + ".c3_b", true, NBc * 4);
+    b.c4_w = wptr(m, p + ".c4_w", true, 2 * NB2 * c * 2);
+    b.c4_b = (const float*)wptr(m, p + ".c4_b", true, NB2 * 4);
+    b.c5_w = wptr(m, p + ".c5_w", true, 2 * NBc * c * 2);
+    b.c5_b = (const float*)wptr(m, p + ".c5_b", true, NBc * 4);
+    return m->err.empty();
+}
+
+bool naf_bind_weights(ira_model* m) {
+    const ira_nafnet_config& c = m->ncfg;
+    const int L = c.n_levels;
+    m->err.clear();
+    m->intro_w = (const float*)wptr(m, "intro_w", true, (size_t)c.width * c.img_channel * 9 * 4);
+    m->intro_b = (const float*)wptr(m, "intro_b", true, (size_t)c.width * 4);
+    m->ending_w = wptr(m, "ending_w", true, (size_t)2 * 9 * up32(c.img_channel) * c.width * 2);
+    m->ending_b = (const float*)wptr(m, "ending_b", true, (size_t)up32(c.img_channel) * 4);
+    if (!m->intro_w || !m->intro_b || !m->ending_w || !m->ending_b) return false;
+    m->nenc.assign(L, {}); m->ndec.assign(L, {});
+    m->ndown_w.assign(L, nullptr); m->ndown_b.assign(L, nullptr); m->nup_w.assign(L, nullptr);
+    int ch = c.width;
+    for (int i = 0; i < L; ++i) {
+        m->nenc[i].resize(c.enc_blk_nums[i]);
+        for (int k = 0; k < c.enc_blk_nums[i]; ++k)
+            if (!naf_load_block(m, "enc." + std::to_string(i) + "." + std::to_string(k), ch, m->nenc[i][k])) return false;
+        m->ndown_w[i] = wptr(m, "down." + std::to_string(i) + "_w", true, (size_t)2 * up32(2 * ch) * 4 * ch * 2);
+        m->ndown_b[i] = (const float*)wptr(m, "down." + std::to_string(i) + "_b", true, (size_t)up32(2 * ch) * 4);
+        if (!m->ndown_w[i] || !m->ndown_b[i]) return false;
+        ch *= 2;
+    }
+    m->nmid.resize(c.middle_blk_num);
+    for (int k = 0; k < c.middle_blk_num; ++k)
+        if (!naf_load_block(m, "mid." + std::to_string(k), ch, m->nmid[k])) return false;
+    for (int i = 0; i < L; ++i) {
+        m->nup_w[i] = wptr(m, "up." + std::to_string(i) + "_w", true, (size_t)2 * up32(2 * ch) * ch * 2);
+        if (!m->nup_w[i]) return false;
+        ch /= 2;
+        m->ndec[i].resize(c.dec_blk_nums[i]);
+        for (int k = 0; k < c.dec_blk_nums[i]; ++k)
+            if (!naf_load_block(m, "dec." + std::to_string(i) + "." + std::to_string(k), ch, m->ndec[i][k])) return false;
+    }
+    return true;
+}
+
+// (H, W): padded size, multiples of 2^L
+int naf_ensure_workspace(ira_model* m, int T, int H, int W) {
+    if (m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W) return IRA_OK;
+    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
+    const ira_nafnet_config& c = m->ncfg;
+    const int L = c.n_levels;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    const size_t t = (size_t)T;
+    std::vector<size_t> o_x(L + 1);
+    size_t mt1 = 0, mg = 0, mpart = 0, mM = 0, ms = 0;
+    for (int l = 0; l <= L; ++l) {
+        const size_t ch = (size_t)c.width << l, P = (size_t)(H >> l) * (W >> l);
+        o_x[l] = take(t * P * ch * 4);
+        mt1 = std::max(mt1, t * P * 2 * ch * 2);
+        mg = std::max(mg, t * P * ch * 2);
+        mpart = std::max(mpart, t * (size_t)ira::naf_dw_sg_blocks(H >> l, W >> l, (int)ch) * ch * 4);
+        mM = std::max(mM, t * 2 * up32((int)ch) * ch * 2);
+        ms = std::max(ms, t * ch * 4);
+    }
+    const size_t o_t1 = take(mt1), o_g = take(mg), o_p = take(mpart), o_M = take(mM), o_s = take(ms);
+    const size_t o_pi = take(t * H * W * c.img_channel * 4), o_po = take(t * H * W * c.img_channel * 4);
+    hipError_t e = hipMalloc((void**)&m->ws, off);
+    if (e != hipSuccess) {
+        m->ws = nullptr; m->ws_T = 0;
+        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, H, W, hipGetErrorString(e));
+    }
+    m->ws_bytes = off; m->ws_T = T; m->ws_H = H; m->ws_W = W;
+    char* b = m->ws;
+    m->nx.resize(L + 1);
+    for (int l = 0; l <= L; ++l) m->nx[l] = (float*)(b + o_x[l]);
+    m->hp = b + o_t1; m->g = b + o_g; m->part = (float*)(b + o_p); m->M = b + o_M; m->nsca = (float*)(b + o_s);
+    m->npad_in = (float*)(b + o_pi); m->npad_out = (float*)(b + o_po);
+    HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));      // rows >= c of a 32-row block are MFMA padding
+    return IRA_OK;
+}
+
+// one NAFBlock in place on x (NAFNet_arch.py:198-219)
+int naf_run_block(ira_model* m, const NBlk& b, float* x, int T, int H, int W, int c) {
+    const int P = H * W, NBc = up32(c) / 32, NB2 = up32(2 * c) / 32;
+    char k_[6][64];
+    if (m->profile) {
+        const char* fam[6] = {"naf_ln_conv1", "naf_dw_gate", "naf_sca_fold", "naf_conv3_res", "naf_ln_conv4", "naf_gate_conv5_res"};
+        for (int i = 0; i < 6; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], c, H, W, T);
+    } else {
+        for (int i = 0; i < 6; ++i) k_[i][0] = 0;
+    }
+    hipStream_t st = m->st;
+    const int bpt = ira::naf_dw_sg_blocks(H, W, c);
+    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, c, b.c1_w, b.c1_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
+    RUN(m, k_[1], ira::launch_naf_dw_sg(st, m->hp, b.dw_w, b.dw_b, m->g, m->part, T, H, W, c));
+    RUN(m, k_[2], ira::launch_naf_sca_fold(st, m->part, bpt, (long)P, b.sca_w, b.sca_b, b.c3_w, b.beta, m->nsca, m->M, T, c, NBc));
+    RUN(m, k_[3], ira::launch_naf_pw(st, 0, 0, m->g, c, m->M, 2L * NBc * 32 * c, b.c3_b, x, x, c, NBc, T, H, W));
+    RUN(m, k_[4], ira::launch_pw_kres(st, x, true, 2, c, b.c4_w, b.c4_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
+    RUN(m, k_[5], ira::launch_naf_pw(st, 1, 0, m->hp, c, b.c5_w, 0, b.c5_b, x, x, c, NBc, T, H, W));
+    return IRA_OK;
+}
+
+// NAFNet.forward (:301-326) on device NHWC fp32 (T, H, W, img_channel), any H, W (zero padded to 2^L here)
+int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    const ira_nafnet_config& c = m->ncfg;
+    const int L = c.n_levels, ps = 1 << L;
+    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
+    const int Hp = (H + ps - 1) / ps * ps, Wp = (W + ps - 1) / ps * ps;          // check_image_size :356-361
+    int rc = naf_ensure_workspace(m, T, Hp, Wp);
+    if (rc != IRA_OK) return rc;
+    hipStream_t st = m->st;
+    const bool padded = (Hp != H) || (Wp != W);
+    const float* xin = in;
+    float* xout = out;
+    if (padded) {
+        RUN(m, "naf_pad", ira::launch_naf_pad_crop(st, in, m->npad_in, T, H, W, Hp, Wp, c.img_channel));
+        xin = m->npad_in; xout = m->npad_out;
+    }
+    auto nb = [](int N) { return up32(N) / 32; };
+    RUN(m, "naf_intro3x3", ira::launch_embed(st, xin, m->intro_w, m->intro_b, m->nx[0], T, Hp, Wp, c.img_channel, c.width));   // :305
+    int ch = c.width, h = Hp, w = Wp;
+    for (int l = 0; l < L; ++l) {                                                                   // :309-312
+        for (const NBlk& b : m->nenc[l]) if ((rc = naf_run_block(m, b, m->nx[l], T, h, w, ch))) return rc;
+        RUN(m, "naf_down2x2", ira::launch_naf_pw(st, 2, 0, m->nx[l], 4 * ch, m->ndown_w[l], 0, m->ndown_b[l], nullptr, m->nx[l + 1],
+                                                 2 * ch, nb(2 * ch), T, h / 2, w / 2));
+        ch *= 2; h /= 2; w /= 2;
+    }
+    for (const NBlk& b : m->nmid) if ((rc = naf_run_block(m, b, m->nx[L], T, h, w, ch))) return rc;  // :314
+    for (int i = 0; i < L; ++i) {                                                                   // :316-321
+        const int l = L - 1 - i;
+        // x = PixelShuffle(conv1x1(x)) + enc_skip, written over the skip buffer
+        RUN(m, "naf_up_shuffle_add", ira::launch_naf_pw(st, 3, 1, m->nx[l + 1], ch, m->nup_w[i], 0, nullptr, m->nx[l], m->nx[l],
+                                                        2 * ch, nb(2 * ch), T, h, w));
+        ch /= 2; h *= 2; w *= 2;
+        for (const NBlk& b : m->ndec[i]) if ((rc = naf_run_block(m, b, m->nx[l], T, h, w, ch))) return rc;
+    }
+    RUN(m, "naf_ending3x3", ira::launch_conv3x3(st, m->nx[0], m->ending_w, m->ending_b, xin, xout, 3, T, Hp, Wp, c.width,
+                                                c.img_channel, nb(c.img_channel)));                  // :323-324
+    if (padded) RUN(m, "naf_crop", ira::launch_naf_pad_crop(st, m->npad_out, out, T, Hp, Wp, H, W, c.img_channel));   // :326
+    return IRA_OK;
+}
+
+int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    return m->arch == 1 ? naf_forward_enqueue(m, in, T, H, W, out) : restormer_forward_enqueue(m, in, T, H, W, out);
 }
 
 struct Plan { int Hp, Wp, th, tw, sh, sw, n_rows, n_cols; };
@@ -417,6 +598,57 @@ int restore_tiles_enqueue(ira_model* m, const uint8_t* frame_dev, int h, int w, 
 
 }  // namespace
 
+// device checks, blob table of contents, stream / events, weight upload: common to every architecture
+static int create_common(int device, const void* blob, size_t bytes, ira_model** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return gfail(IRA_ERR_NO_DEVICE, "no HIP device visible: libira_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return gfail(IRA_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess || strncmp(pr.gcnArchName, "gfx950", 6) != 0)
+        return gfail(IRA_ERR_NO_DEVICE, "device %d is '%s', this library carries gfx950 code only", device, pr.gcnArchName);
+
+    // parse blob table of contents
+    if (bytes < sizeof(BlobHeader)) return gfail(IRA_ERR_WEIGHTS, "weight blob too small");
+    const BlobHeader* hd = (const BlobHeader*)blob;
+    if (memcmp(hd->magic, "IRAWGT1", 8) != 0) return gfail(IRA_ERR_WEIGHTS, "weight blob: bad magic");
+    const size_t toc_end = sizeof(BlobHeader) + (size_t)hd->n_entries * sizeof(TocEntry);
+    if (toc_end > bytes) return gfail(IRA_ERR_WEIGHTS, "weight blob: truncated table of contents");
+
+    ira_model* m = new ira_model();
+    m->device = device;
+    const TocEntry* te = (const TocEntry*)((const char*)blob + sizeof(BlobHeader));
+    for (uint32_t i = 0; i < hd->n_entries; ++i) {
+        if (te[i].offset + te[i].nbytes > bytes || te[i].offset % 256 != 0) {
+            delete m; return gfail(IRA_ERR_WEIGHTS, "weight blob: entry %u out of bounds / misaligned", i);
+        }
+        char nm[113]; memcpy(nm, te[i].name, 112); nm[112] = 0;
+        m->toc[nm] = {(size_t)te[i].offset, (size_t)te[i].nbytes};
+    }
+    auto bail = [&](int code, const std::string& why) {
+        g_err = why;
+        if (m->wblob) hipFree(m->wblob);
+        if (m->st) hipStreamDestroy(m->st);
+        if (m->ev0) hipEventDestroy(m->ev0);
+        if (m->ev1) hipEventDestroy(m->ev1);
+        if (m->pev0) hipEventDestroy(m->pev0);
+        if (m->pev1) hipEventDestroy(m->pev1);
+        delete m;
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->pev0) != hipSuccess ||
+        hipEventCreate(&m->pev1) != hipSuccess)
+        return bail(IRA_ERR_HIP, "hipEventCreate failed");
+    if ((e = hipMalloc((void**)&m->wblob, bytes)) != hipSuccess) { m->wblob = nullptr; return bail(IRA_ERR_OOM, std::string("weights hipMalloc: ") + hipGetErrorString(e)); }
+    m->wbytes = bytes;
+    if ((e = hipMemcpy(m->wblob, blob, bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("weights upload: ") + hipGetErrorString(e));
+    *out = m;
+    return IRA_OK;
+}
+
 // =============================================================================================
 extern "C" {
 
@@ -454,52 +686,41 @@ int ira_model_create(int device, const ira_restormer_config* cfg, const void* bl
         if ((2 * cfg->dim) % cfg->heads[0] != 0 || (c != 16 && c != 32 && c != 48 && c != 96))
             return gfail(IRA_ERR_ARG, "decoder level 1: per-head channels %d not in {16,32,48,96}", c);
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return gfail(IRA_ERR_NO_DEVICE, "no HIP device visible: libira_hip has no CPU fallback");
-    if (device < 0 || device >= ndev) return gfail(IRA_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, device) != hipSuccess || strncmp(pr.gcnArchName, "gfx950", 6) != 0)
-        return gfail(IRA_ERR_NO_DEVICE, "device %d is '%s', this library carries gfx950 code only", device, pr.gcnArchName);
-
-    // parse blob table of contents
-    if (bytes < sizeof(BlobHeader)) return gfail(IRA_ERR_WEIGHTS, "weight blob too small");
-    const BlobHeader* hd = (const BlobHeader*)blob;
-    if (memcmp(hd->magic, "IRAWGT1", 8) != 0) return gfail(IRA_ERR_WEIGHTS, "weight blob: bad magic");
-    const size_t toc_end = sizeof(BlobHeader) + (size_t)hd->n_entries * sizeof(TocEntry);
-    if (toc_end > bytes) return gfail(IRA_ERR_WEIGHTS, "weight blob: truncated table of contents");
-
-    ira_model* m = new ira_model();
-    m->device = device; m->cfg = *cfg;
-    const TocEntry* te = (const TocEntry*)((const char*)blob + sizeof(BlobHeader));
-    for (uint32_t i = 0; i < hd->n_entries; ++i) {
-        if (te[i].offset + te[i].nbytes > bytes || te[i].offset % 256 != 0) {
-            delete m; return gfail(IRA_ERR_WEIGHTS, "weight blob: entry %u out of bounds / misaligned", i);
-        }
-        char nm[113]; memcpy(nm, te[i].name, 112); nm[112] = 0;
-        m->toc[nm] = {(size_t)te[i].offset, (size_t)te[i].nbytes};
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 0; m->cfg = *cfg;
+    if (!bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
     }
-    auto bail = [&](int code, const std::string& why) {
-        g_err = why;
-        if (m->wblob) hipFree(m->wblob);
-        if (m->st) hipStreamDestroy(m->st);
-        if (m->ev0) hipEventDestroy(m->ev0);
-        if (m->ev1) hipEventDestroy(m->ev1);
-        if (m->pev0) hipEventDestroy(m->pev0);
-        if (m->pev1) hipEventDestroy(m->pev1);
-        delete m;
-        return code;
-    };
-    hipError_t e;
-    if ((e = hipSetDevice(device)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    if ((e = hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-    if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess || hipEventCreate(&m->pev0) != hipSuccess ||
-        hipEventCreate(&m->pev1) != hipSuccess)
-        return bail(IRA_ERR_HIP, "hipEventCreate failed");
-    if ((e = hipMalloc((void**)&m->wblob, bytes)) != hipSuccess) { m->wblob = nullptr; return bail(IRA_ERR_OOM, std::string("weights hipMalloc: ") + hipGetErrorString(e)); }
-    m->wbytes = bytes;
-    if ((e = hipMemcpy(m->wblob, blob, bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(IRA_ERR_HIP, std::string("weights upload: ") + hipGetErrorString(e));
-    if (!bind_weights(m)) return bail(IRA_ERR_WEIGHTS, m->err.empty() ? "weight blob: missing entries" : m->err);
+    *out = m;
+    return IRA_OK;
+}
+
+
+int ira_nafnet_create(int device, const ira_nafnet_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_nafnet_create: NULL argument");
+    *out = nullptr;
+    if (cfg->img_channel != 1 && cfg->img_channel != 3) return gfail(IRA_ERR_ARG, "img_channel must be 1 or 3, got %d", cfg->img_channel);
+    if (cfg->width < 16 || (cfg->width & (cfg->width - 1)) != 0)
+        return gfail(IRA_ERR_ARG, "width must be a power of two >= 16, got %d", cfg->width);
+    if (cfg->n_levels < 1 || cfg->n_levels > IRA_NAFNET_MAX_LEVELS || (cfg->width << cfg->n_levels) > 2048)
+        return gfail(IRA_ERR_ARG, "n_levels=%d out of range (1..%d, width*2^levels <= 2048)", cfg->n_levels, IRA_NAFNET_MAX_LEVELS);
+    if (cfg->middle_blk_num < 0) return gfail(IRA_ERR_ARG, "middle_blk_num must be >= 0");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->enc_blk_nums[i] < 0 || cfg->dec_blk_nums[i] < 0) return gfail(IRA_ERR_ARG, "block counts must be >= 0");
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 1; m->ncfg = *cfg;
+    m->cfg.inp_channels = m->cfg.out_channels = cfg->img_channel;      // what the harness entry points check
+    if (!naf_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
     *out = m;
     return IRA_OK;
 }
@@ -545,8 +766,10 @@ int ira_forward_device(ira_model_t* m, const float* in, int B, int H, int W, flo
 int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, float* out) {
     ENTER(m);
     if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_forward: NULL buffer");
-    if (C != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "ira_forward: C=%d but the model has inp_channels=%d", C, m->cfg.inp_channels);
-    if (B <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7)) return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
+    const int ic = m->arch == 1 ? m->ncfg.img_channel : m->cfg.inp_channels;
+    if (C != ic) return m->fail(IRA_ERR_ARG, "ira_forward: C=%d but the model has inp_channels=%d", C, ic);
+    if (B <= 0 || H <= 0 || W <= 0 || (m->arch == 0 && ((H & 7) || (W & 7))))
+        return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
     const size_t n = (size_t)B * C * H * W;
     int rc = ensure_scratch(m, 3 * al256(n * 4));
     if (rc != IRA_OK) return rc;
@@ -699,6 +922,11 @@ int ira_op_pw_kres(ira_model_t* m, const void* x, int in_f32, int ln_mode, int K
     OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P));
 }
 
+int ira_op_pw_kres_eps(ira_model_t* m, const void* x, int in_f32, int ln_mode, int K, const void* W, const float* bias,
+                       void* y, int y_stride, int n_store, int NB, int T, int P, float eps) {
+    OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps));
+}
+
 int ira_op_pw_nres(ira_model_t* m, const void* x0, int K0, const void* x1, int K1, int in_f32, const void* W,
                    long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T, int P) {
     OP_BODY(m, "op", ira::launch_pw_nres(m->st, x0, K0, x1, K1, in_f32 != 0, W, w_tile_stride, bias, resid, y, N, NB, T, P));
@@ -759,6 +987,22 @@ int ira_op_embed(ira_model_t* m, const float* in, const float* w, const float* b
 
 int ira_op_concat2(ira_model_t* m, const float* a, int Ca, const float* b, int Cb, float* out, long npx) {
     OP_BODY(m, "op", ira::launch_concat2(m->st, a, Ca, b, Cb, out, npx));
+}
+
+int ira_op_naf_pw(ira_model_t* m, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
+                  const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+    OP_BODY(m, "op", ira::launch_naf_pw(m->st, inmode, outmode, x, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg));
+}
+
+int ira_op_naf_dw_sg(ira_model_t* m, const void* in, const float* w, const float* bias, void* out, float* part, int T, int H,
+                     int W, int c, int* blocks_per_image) {
+    if (blocks_per_image) *blocks_per_image = ira::naf_dw_sg_blocks(H, W, c);
+    OP_BODY(m, "op", ira::launch_naf_dw_sg(m->st, in, w, bias, out, part, T, H, W, c));
+}
+
+int ira_op_naf_sca_fold(ira_model_t* m, const float* part, int blocks_per_image, long npx, const float* wsca, const float* bsca,
+                        const float* w3, const float* beta, float* s, void* M, int T, int c, int NB) {
+    OP_BODY(m, "op", ira::launch_naf_sca_fold(m->st, part, blocks_per_image, npx, wsca, bsca, w3, beta, s, M, T, c, NB));
 }
 
 }  // extern "C"

@@ -25,6 +25,17 @@ class IraConfig(C.Structure):
     ]
 
 
+NAFNET_MAX_LEVELS = 6
+
+
+class IraNafnetConfig(C.Structure):
+    _fields_ = [
+        ('img_channel', C.c_int32), ('width', C.c_int32), ('n_levels', C.c_int32),
+        ('enc_blk_nums', C.c_int32 * NAFNET_MAX_LEVELS), ('middle_blk_num', C.c_int32),
+        ('dec_blk_nums', C.c_int32 * NAFNET_MAX_LEVELS),
+    ]
+
+
 _vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 _pi = C.POINTER(C.c_int)
 
@@ -32,6 +43,7 @@ _pi = C.POINTER(C.c_int)
 SIGNATURES = {
     'ira_device_count': (_i, [_pi]),
     'ira_model_create': (_i, [_i, C.POINTER(IraConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_nafnet_create': (_i, [_i, C.POINTER(IraNafnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_model_destroy': (_i, [_vp]),
     'ira_last_error': (C.c_char_p, [_vp]),
     'ira_sync': (_i, [_vp]),
@@ -59,6 +71,10 @@ SIGNATURES = {
     'ira_set_fused_ffn': (_i, [_vp, _i]),
     'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     'ira_op_concat2': (_i, [_vp, _vp, _i, _vp, _i, _vp, _l]),
+    'ira_op_pw_kres_eps': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float]),
+    'ira_op_naf_pw': (_i, [_vp, _i, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_naf_dw_sg': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _pi]),
+    'ira_op_naf_sca_fold': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
 }
 
 _lib = None

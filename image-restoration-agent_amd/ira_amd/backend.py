@@ -31,23 +31,19 @@ def _cfg_struct(cfg: RestormerConfig) -> IraConfig:
     return s
 
 
-class RestormerBackend:
-    """One Restormer on one MI355X.  ``state_dict``: the reference's name -> tensor mapping
-    (torch tensors or numpy arrays), e.g. ``torch.load(path)['params']``."""
+class _Backend:
+    """Shared handle plumbing: one libira_hip model on one MI355X (one HIP stream)."""
 
-    def __init__(self, cfg: RestormerConfig, state_dict, device: int = 0):
+    def _create(self, device: int, create_fn, cfg_struct, blob: bytes, what: str):
         self._lib = _capi.load_library()
-        self.cfg = cfg
         self.device = int(device)
         self._h = C.c_void_p(None)
         if _capi.device_count() <= 0:
             raise IraError("no gfx950 (MI355X) device visible; this backend has no CPU fallback")
-        blob = pack_blob(state_dict, cfg)
-        cs = _cfg_struct(cfg)
         h = C.c_void_p(None)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        rc = self._lib.ira_model_create(self.device, C.byref(cs), buf, len(blob), C.byref(h))
-        check(rc, None, 'ira_model_create')
+        rc = getattr(self._lib, create_fn)(self.device, C.byref(cfg_struct), buf, len(blob), C.byref(h))
+        check(rc, None, what)
         self._h = h
 
     # -- life cycle
@@ -152,3 +148,22 @@ class RestormerBackend:
         n = C.c_size_t(0)
         self._ck(self._lib.ira_memory_bytes(self._h, C.byref(n)), 'ira_memory_bytes')
         return int(n.value)
+
+
+class RestormerBackend(_Backend):
+    """One Restormer on one MI355X.  ``state_dict``: the reference's name -> tensor mapping
+    (torch tensors or numpy arrays), e.g. ``torch.load(path)['params']``."""
+
+    def __init__(self, cfg: RestormerConfig, state_dict, device: int = 0):
+        self.cfg = cfg
+        self._create(device, 'ira_model_create', _cfg_struct(cfg), pack_blob(state_dict, cfg), 'ira_model_create')
+
+
+class NAFNetBackend(_Backend):
+    """One NAFNet on one MI355X (NAFNet_arch.py:249-326).  ``forward`` takes any H, W: the network
+    pads to a multiple of 2**len(enc_blk_nums) with zeros and crops (check_image_size, :356-361)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .nafnet import pack_nafnet_blob, nafnet_cfg_struct
+        self.cfg = cfg
+        self._create(device, 'ira_nafnet_create', nafnet_cfg_struct(cfg), pack_nafnet_blob(state_dict, cfg), 'ira_nafnet_create')

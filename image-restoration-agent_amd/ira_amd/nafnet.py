@@ -80,3 +80,75 @@ def seeded_tensor(seed, name, shape):
 
 def seeded_state_dict(cfg: NAFNetConfig, seed: int = 0):
     return OrderedDict((n, seeded_tensor(seed, n, s)) for n, s in state_dict_spec(cfg))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# packer: reference state_dict -> device blob (layouts of csrc/ira_nafnet.hip; container format of ira_amd.pack)
+
+def nafnet_cfg_struct(cfg: NAFNetConfig):
+    from ._capi import IraNafnetConfig, NAFNET_MAX_LEVELS
+    L = len(cfg.enc_blk_nums)
+    if L != len(cfg.dec_blk_nums) or not 1 <= L <= NAFNET_MAX_LEVELS:
+        raise ValueError(f"enc_blk_nums / dec_blk_nums must have the same length in 1..{NAFNET_MAX_LEVELS}")
+    s = IraNafnetConfig()
+    s.img_channel, s.width, s.n_levels, s.middle_blk_num = cfg.img_channel, cfg.width, L, cfg.middle_blk_num
+    for i in range(L):
+        s.enc_blk_nums[i] = cfg.enc_blk_nums[i]
+        s.dec_blk_nums[i] = cfg.dec_blk_nums[i]
+    return s
+
+
+def pack_nafnet_block(sd, p: str, c: int, out: dict, name: str):
+    """One NAFBlock (NAFNet_arch.py:163-219).  Folds: LayerNorm2d gain/bias into conv1 / conv4
+    (conv(g*n + b) = (W diag g) n + (W b + bias)); beta into conv3's bias (its weight is folded per image on the
+    device together with the channel attention); gamma into conv5."""
+    from .pack import frag_major, split16, up32, _np, _pad_rows, _dw_pack
+    f64 = lambda k: _np(sd[f'{p}.{k}']).astype(np.float64)
+    for norm, conv, dst in (('norm1', 'conv1', 'c1'), ('norm2', 'conv4', 'c4')):
+        w = f64(f'{conv}.weight')[:, :, 0, 0]
+        out[f'{name}.{dst}_w'] = frag_major(split16(_pad_rows(w * f64(f'{norm}.weight')[None, :], up32(2 * c))))
+        out[f'{name}.{dst}_b'] = _pad_rows((w @ f64(f'{norm}.bias') + f64(f'{conv}.bias')).astype(np.float32), up32(2 * c))
+    out[f'{name}.dw_w'] = _dw_pack(_np(sd[f'{p}.conv2.weight']))
+    out[f'{name}.dw_b'] = _np(sd[f'{p}.conv2.bias']).astype(np.float32)
+    out[f'{name}.sca_w'] = np.ascontiguousarray(_np(sd[f'{p}.sca.1.weight'])[:, :, 0, 0])
+    out[f'{name}.sca_b'] = _np(sd[f'{p}.sca.1.bias']).astype(np.float32)
+    beta, gamma = f64('beta').reshape(-1), f64('gamma').reshape(-1)
+    out[f'{name}.c3_w'] = np.ascontiguousarray(_np(sd[f'{p}.conv3.weight'])[:, :, 0, 0])
+    out[f'{name}.beta'] = beta.astype(np.float32)
+    out[f'{name}.c3_b'] = _pad_rows((beta * f64('conv3.bias')).astype(np.float32), up32(c))
+    out[f'{name}.c5_w'] = frag_major(split16(_pad_rows(gamma[:, None] * f64('conv5.weight')[:, :, 0, 0], up32(c))))
+    out[f'{name}.c5_b'] = _pad_rows((gamma * f64('conv5.bias')).astype(np.float32), up32(c))
+
+
+def pack_nafnet_arrays(sd, cfg: NAFNetConfig) -> dict:
+    from .pack import frag_major, split16, up32, _np, _pad_rows, _conv3_pack
+    out: dict = {}
+    out['intro_w'] = np.ascontiguousarray(_np(sd['intro.weight']))
+    out['intro_b'] = _np(sd['intro.bias']).astype(np.float32)
+    out['ending_w'] = _conv3_pack(_np(sd['ending.weight']))
+    out['ending_b'] = _pad_rows(_np(sd['ending.bias']).astype(np.float32), up32(cfg.img_channel))
+    ch = cfg.width
+    for i, n in enumerate(cfg.enc_blk_nums):
+        for k in range(n):
+            pack_nafnet_block(sd, f'encoders.{i}.{k}', ch, out, f'enc.{i}.{k}')
+        w = _np(sd[f'downs.{i}.weight']).astype(np.float64)                  # [2c][c][2][2] -> [2c][(dy,dx,ci)]
+        w = w.transpose(0, 2, 3, 1).reshape(2 * ch, 4 * ch)
+        out[f'down.{i}_w'] = frag_major(split16(_pad_rows(w, up32(2 * ch))))
+        out[f'down.{i}_b'] = _pad_rows(_np(sd[f'downs.{i}.bias']).astype(np.float32), up32(2 * ch))
+        ch *= 2
+    for k in range(cfg.middle_blk_num):
+        pack_nafnet_block(sd, f'middle_blks.{k}', ch, out, f'mid.{k}')
+    for i, n in enumerate(cfg.dec_blk_nums):
+        w = _np(sd[f'ups.{i}.0.weight']).astype(np.float64)[:, :, 0, 0]     # [2ch][ch]; PixelShuffle: row = cc*4 + q
+        nq = (2 * ch) // 4
+        w = w.reshape(nq, 4, ch).transpose(1, 0, 2).reshape(2 * ch, ch)     # row' = q*nq + cc
+        out[f'up.{i}_w'] = frag_major(split16(_pad_rows(w, up32(2 * ch))))
+        ch //= 2
+        for k in range(n):
+            pack_nafnet_block(sd, f'decoders.{i}.{k}', ch, out, f'dec.{i}.{k}')
+    return out
+
+
+def pack_nafnet_blob(sd, cfg: NAFNetConfig) -> bytes:
+    from .pack import blob_from_arrays
+    return blob_from_arrays(pack_nafnet_arrays(sd, cfg))

@@ -159,7 +159,11 @@ def pack_arrays(sd, cfg: RestormerConfig) -> dict:
 
 
 def pack_blob(sd, cfg: RestormerConfig) -> bytes:
-    arrays = pack_arrays(sd, cfg)
+    return blob_from_arrays(pack_arrays(sd, cfg))
+
+
+def blob_from_arrays(arrays: dict) -> bytes:
+    """Container: magic, table of contents (128-byte entries: name, offset, nbytes), 256-byte-aligned arrays."""
     names = list(arrays.keys())
     header_bytes = 16 + 128 * len(names)
     off = (header_bytes + 255) // 256 * 256

@@ -57,6 +57,18 @@ typedef struct ira_restormer_config {
     int32_t dual_pixel_task;         /* must be 0 (not dispatched by the agent) */
 } ira_restormer_config;
 
+/* Constructor arguments of the reference NAFNet (X-Restormer/xrestormer/archs/NAFNet_arch.py:251): SURVEY 8 row a11 /
+ * BASELINE config 2.  n_levels = len(enc_blk_nums) == len(dec_blk_nums). */
+#define IRA_NAFNET_MAX_LEVELS 6
+typedef struct ira_nafnet_config {
+    int32_t img_channel;                              /* 3 */
+    int32_t width;                                    /* 32: a power of two >= 16 */
+    int32_t n_levels;                                 /* 4 */
+    int32_t enc_blk_nums[IRA_NAFNET_MAX_LEVELS];      /* {2,2,4,8} */
+    int32_t middle_blk_num;                           /* 12 */
+    int32_t dec_blk_nums[IRA_NAFNET_MAX_LEVELS];      /* {2,2,2,2} */
+} ira_nafnet_config;
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
@@ -68,6 +80,12 @@ int ira_device_count(int* count);
  * model.load_state_dict(...); model.eval()  (demo.py:95-103, model_serving.py:101-124). */
 int ira_model_create(int device, const ira_restormer_config* cfg,
                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* Same for NAFNet (blob from ira_amd/nafnet.py::pack_nafnet_blob).  The returned handle is used with the same
+ * ira_forward / ira_forward_device / measurement / ira_model_destroy entry points; for NAFNet they accept any H, W
+ * (the network zero-pads to a multiple of 2^n_levels and crops: NAFNet_arch.py:303,326,356-361).
+ * replaces: NAFNet(**opt); load_state_dict; eval  (NAFNet_arch.py:251-299). */
+int ira_nafnet_create(int device, const ira_nafnet_config* cfg,
+                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
 int ira_model_destroy(ira_model_t* model);
 
 /* Text of the last error on this handle (or, with model == NULL, of the last failed call that had
@@ -203,6 +221,34 @@ int ira_op_embed(ira_model_t* m, const float* in_dev, const float* w_dev, const 
 
 /* torch.cat([a, b], 1) on fp32 NHWC (restormer_arch.py:270). */
 int ira_op_concat2(ira_model_t* m, const float* a_dev, int Ca, const float* b_dev, int Cb, float* out_dev, long npx);
+
+/* ira_op_pw_kres with the LayerNorm epsilon as an argument (NAFNet's LayerNorm2d uses 1e-6, NAFNet_arch.py:138;
+ * Restormer's 1e-5). */
+int ira_op_pw_kres_eps(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K,
+                       const void* W_f16_dev, const float* bias_dev, void* y_f16_dev, int y_stride,
+                       int n_store, int NB, int T, int P, float eps);
+
+/* ---- NAFNet kernels (NAFNet_arch.py:158-326)
+ * Pointwise contraction on an MFMA pixel grid of T x Hg x Wg pixels, W packed like every 1x1 here
+ * ([2 planes][NBtot][K/16][64][8], per image if w_tile_stride != 0), fp32 result.
+ * inmode 0: x fp16 (T,Hg,Wg,K).  1: x fp16 (T,Hg,Wg,2K), operand = x[..,:K]*x[..,K:] (SimpleGate :158-161).
+ *        2: x fp32 (T,2Hg,2Wg,K/4), k = (dy*2+dx)*(K/4)+ci: the 2x2 stride-2 "downs" conv (:275-277).  3: x fp32 (T,Hg,Wg,K).
+ * outmode 0: y (T,Hg,Wg,N) = acc + bias (+ resid).  1: y (T,2Hg,2Wg,N/4), row n = (2sy+sx)*(N/4)+cc goes to sub-pixel
+ *        (sy,sx) channel cc (PixelShuffle(2), :286-291, rows permuted by the packer), + resid (the encoder skip, :320). */
+int ira_op_naf_pw(ira_model_t* m, int inmode, int outmode, const void* x_dev, int K, const void* W_f16_dev,
+                  long w_tile_stride, const float* bias_dev, const float* resid_dev, float* y_dev, int N, int NBtot,
+                  int T, int Hg, int Wg);
+
+/* conv2 (depthwise 3x3, bias) + SimpleGate + partial channel sums for the global average pool (:202-205):
+ * in fp16 (T,H,W,2c), w fp32 [9][2c], out fp16 (T,H,W,c), part fp32 [T][blocks_per_image][c] (returned count). */
+int ira_op_naf_dw_sg(ira_model_t* m, const void* in_dev, const float* w_dev, const float* bias_dev, void* out_dev,
+                     float* part_dev, int T, int H, int W, int c, int* blocks_per_image);
+
+/* s[t] = sca_w . mean_px(g[t]) + sca_b (:175-179);  M[t] = diag(beta) W3 diag(s[t]) packed hi/lo fragment-major
+ * [T][2][NB][c/16][64][8] (the channel attention and the beta scale folded into conv3, :205-211). */
+int ira_op_naf_sca_fold(ira_model_t* m, const float* part_dev, int blocks_per_image, long npx, const float* wsca_dev,
+                        const float* bsca_dev, const float* w3_dev, const float* beta_dev, float* s_dev, void* M_f16_dev,
+                        int T, int c, int NB);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,240 @@
+"""NAFNet (SURVEY 8 row a11 / BASELINE config 2) on a real MI355X, through the C ABI: the NAFNet-specific kernels against
+plain torch fp32 statements of the same ops (NAFNet_arch.py cited per test), and the whole network against (a) the
+goldens produced by the reference module (tests/golden/make_golden_nafnet.py) and (b) the CPU oracle on fresh inputs.
+
+Bars: fp32 outputs of weight contractions rtol 2e-5 (hi/lo fp16 weight planes, identical fp16 rounding of activations on
+both sides); fp16-stored outputs rtol 2e-3; whole network PSNR(build, reference) >= 58 dB and
+|PSNR(build_u8, clean) - PSNR(ref_u8, clean)| <= 1e-3 dB, the same bars as Restormer (tests/test_gpu_net.py)."""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ira_amd.nafnet import NAFNetConfig, reduced_nafnet_config, seeded_state_dict
+from oracle import restormer_oracle as O
+from oracle.nafnet_oracle import nafnet_forward, layer_norm2d
+from test_gpu_ops import close, dev, ptr, r16, rowperm_pad, split16, up32
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+CASES = sorted(glob.glob(os.path.join(GOLD, 'nafnet_*.npz')))
+
+_cache = {}
+
+
+def backend(cfg, seed):
+    from ira_amd.backend import NAFNetBackend
+    key = (json.dumps(cfg.to_dict(), sort_keys=True), seed)
+    if key not in _cache:
+        if len(_cache) >= 2:
+            _, old = _cache.popitem()
+            old.close()
+        _cache[key] = NAFNetBackend(cfg, seeded_state_dict(cfg, seed), device=0)
+    return _cache[key]
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    cfg = reduced_nafnet_config()
+    return backend(cfg, 1)
+
+
+def nhwc(t):           # (T,C,H,W) -> (T,H,W,C)
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize('c,T,P', [(16, 2, 70), (32, 1, 64), (128, 2, 33), (256, 1, 40), (512, 1, 37)])
+def test_ln2d_conv1(ctx, c, T, P):
+    """LayerNorm2d (eps 1e-6, NAFNet_arch.py:120-134) + conv1/conv4 (c -> 2c, :199-200,213): K up to 512."""
+    g = torch.Generator().manual_seed(c + P)
+    x = torch.randn(T * P, c, generator=g) * 1.3 + 0.2
+    W = torch.randn(2 * c, c, generator=g) / c ** 0.5
+    bias = torch.randn(2 * c, generator=g) * 0.1
+    mu = x.mean(-1, keepdim=True)
+    n = (x - mu) / torch.sqrt(x.var(-1, keepdim=True, unbiased=False) + 1e-6)
+    ref = (r16(n).double() @ W.double().t()).float() + bias
+    NB = up32(2 * c) // 32
+    y = torch.full((T * P, 2 * c), float('nan'), dtype=torch.float16).cuda()
+    xd, Wd, bd = dev(x), dev(split16(rowperm_pad(W, NB * 32))), dev(rowperm_pad(bias[:, None], NB * 32)[:, 0])
+    rc = ctx._lib.ira_op_pw_kres_eps(ctx.handle, ptr(xd), 1, 2, c, ptr(Wd), ptr(bd), ptr(y), 2 * c, 2 * c, NB, T, P, 1e-6)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu().float(), ref, 2e-3)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(16, 2, 9, 13), (32, 1, 16, 16), (64, 3, 7, 5), (256, 1, 6, 10), (512, 2, 4, 4)])
+def test_dw_simplegate_pool(ctx, c, T, H, W):
+    """conv2 (depthwise 3x3 + bias) + SimpleGate + the partial sums of AdaptiveAvgPool2d(1) (:201-205)."""
+    g = torch.Generator().manual_seed(c * 3 + H)
+    x = r16(torch.randn(T, 2 * c, H, W, generator=g))
+    w = torch.randn(2 * c, 1, 3, 3, generator=g) * 0.4
+    b = torch.randn(2 * c, generator=g) * 0.1
+    d = F.conv2d(x, w, b, padding=1, groups=2 * c)
+    gate = d[:, :c] * d[:, c:]
+    xd = dev(nhwc(x).half())
+    wd, bd = dev(w.reshape(2 * c, 9).t().contiguous()), dev(b)
+    out = torch.full((T, H, W, c), float('nan'), dtype=torch.float16).cuda()
+    part = torch.full((T * 4096 * c,), float('nan')).cuda()
+    bpt = C.c_int(0)
+    rc = ctx._lib.ira_op_naf_dw_sg(ctx.handle, ptr(xd), ptr(wd), ptr(bd), ptr(out), ptr(part), T, H, W, c, C.byref(bpt))
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(out.cpu().float(), nhwc(gate), 2e-3)
+    sums = part[:T * bpt.value * c].view(T, bpt.value, c).sum(1).cpu()
+    close(sums, gate.sum((2, 3)), 2e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize('c,T,bpt', [(16, 2, 3), (32, 3, 1024), (128, 1, 7), (512, 2, 5)])
+def test_sca_fold(ctx, c, T, bpt):
+    """sca (mean -> 1x1, :175-179) and M = diag(beta) conv3 diag(s) (:205-211) in the packed hi/lo layout."""
+    from ira_amd.pack import frag_major, split16 as s16
+    g = torch.Generator().manual_seed(c + bpt)
+    part = torch.randn(T, bpt, c, generator=g)
+    npx = 1000
+    wsca, bsca = torch.randn(c, c, generator=g) / c ** 0.5, torch.randn(c, generator=g) * 0.1
+    w3, beta = torch.randn(c, c, generator=g) / c ** 0.5, torch.randn(c, generator=g)
+    mean = part.double().sum(1) / npx
+    s = mean @ wsca.double().t() + bsca.double()
+    NB = up32(c) // 32
+    sd = torch.full((T, c), float('nan')).cuda()
+    M = torch.zeros(T, 2, NB, c // 16, 64, 8, dtype=torch.float16).cuda()
+    pd, a, b_, c_, d_ = dev(part), dev(wsca), dev(bsca), dev(w3), dev(beta)
+    rc = ctx._lib.ira_op_naf_sca_fold(ctx.handle, ptr(pd), bpt, npx, ptr(a), ptr(b_), ptr(c_), ptr(d_), ptr(sd), ptr(M), T, c, NB)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(sd.cpu(), s.float(), 2e-5, atol_scale=1e-5)
+    for t in range(T):
+        Mref = beta.double()[:, None] * w3.double() * sd.cpu().double()[t][None, :]
+        Mp = np.zeros((NB * 32, c)); Mp[:c] = Mref.numpy()
+        want = frag_major(s16(Mp)).astype(np.float64)                 # [2][NB][c/16][64][8]
+        got = M[t].cpu().double().numpy()
+        np.testing.assert_allclose(got[0] + got[1], want[0] + want[1], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[0], want[0], rtol=2e-3, atol=1e-6)
+
+
+def _pw_ref(xb, Wm, bias, N):
+    y = r16(xb).double() @ Wm.double().t()
+    return (y + bias[:N].double()).float() if bias is not None else y.float()
+
+
+@pytest.mark.parametrize('c,T,H,W,per_image', [(16, 2, 5, 7, True), (32, 1, 16, 9, True), (256, 2, 6, 6, True), (512, 1, 5, 5, False)])
+def test_pw_f16_residual(ctx, c, T, H, W, per_image):
+    """x += M g (+ bias): conv3 with the per-image folded matrix + residual (:206-211); N up to 512 (two N splits)."""
+    g = torch.Generator().manual_seed(c + H)
+    P, NB = H * W, up32(c) // 32
+    x = r16(torch.randn(T, P, c, generator=g))
+    Wm = torch.randn(T if per_image else 1, c, c, generator=g) / c ** 0.5
+    bias = rowperm_pad(torch.randn(c, 1, generator=g) * 0.1, NB * 32)[:, 0]
+    res = torch.randn(T, P, c, generator=g)
+    ref = torch.stack([_pw_ref(x[t], Wm[t if per_image else 0], bias, c) for t in range(T)]) + res
+    Wd = dev(torch.stack([split16(rowperm_pad(Wm[i], NB * 32)) for i in range(Wm.shape[0])]))
+    xd, bd, y = dev(x.half()), dev(bias), dev(res)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 0, 0, ptr(xd), c, ptr(Wd), 2 * NB * 32 * c if per_image else 0, ptr(bd), ptr(y), ptr(y),
+                                c, NB, T, H, W)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), ref, 2e-5)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(16, 2, 5, 7), (64, 1, 8, 8), (512, 1, 6, 5)])
+def test_pw_gated_residual(ctx, c, T, H, W):
+    """SimpleGate + conv5 + gamma + residual (:214-219): the gate is applied while the B operand is loaded."""
+    g = torch.Generator().manual_seed(c * 5 + H)
+    P, NB = H * W, up32(c) // 32
+    t2 = r16(torch.randn(T * P, 2 * c, generator=g))
+    Wm = torch.randn(c, c, generator=g) / c ** 0.5
+    bias = rowperm_pad(torch.randn(c, 1, generator=g) * 0.1, NB * 32)[:, 0]
+    res = torch.randn(T * P, c, generator=g)
+    ref = _pw_ref(t2[:, :c] * t2[:, c:], Wm, bias, c) + res
+    td, Wd, bd, y = dev(t2.half()), dev(split16(rowperm_pad(Wm, NB * 32))), dev(bias), dev(res)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 1, 0, ptr(td), c, ptr(Wd), 0, ptr(bd), ptr(y), ptr(y), c, NB, T, H, W)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), ref, 2e-5)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(16, 2, 6, 10), (32, 1, 16, 16), (256, 1, 4, 6)])
+def test_down_conv2x2(ctx, c, T, H, W):
+    """downs[i] = Conv2d(c, 2c, 2, 2) (:275-277) as a K = 4c contraction over the four source pixels."""
+    g = torch.Generator().manual_seed(c * 7 + W)
+    x = torch.randn(T, c, H, W, generator=g)
+    w = torch.randn(2 * c, c, 2, 2, generator=g) / (4 * c) ** 0.5
+    b = torch.randn(2 * c, generator=g) * 0.1
+    ref = F.conv2d(r16(x).double(), w.double(), b.double(), stride=2).float()
+    NB = up32(2 * c) // 32
+    Wm = w.permute(0, 2, 3, 1).reshape(2 * c, 4 * c)
+    xd, Wd, bd = dev(nhwc(x)), dev(split16(rowperm_pad(Wm, NB * 32))), dev(rowperm_pad(b[:, None], NB * 32)[:, 0])
+    y = torch.full((T, H // 2, W // 2, 2 * c), float('nan')).cuda()
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 2, 0, ptr(xd), 4 * c, ptr(Wd), 0, ptr(bd), None, ptr(y), 2 * c, NB, T, H // 2, W // 2)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), nhwc(ref), 2e-5)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(32, 2, 5, 7), (64, 1, 8, 8), (512, 1, 3, 4)])
+def test_up_shuffle_add(ctx, c, T, H, W):
+    """ups[i] = Conv2d(c, 2c, 1, bias=False) + PixelShuffle(2), then x + enc_skip (:286-291,319-320)."""
+    g = torch.Generator().manual_seed(c * 11 + W)
+    x = torch.randn(T, c, H, W, generator=g)
+    w = torch.randn(2 * c, c, 1, 1, generator=g) / c ** 0.5
+    skip = torch.randn(T, c // 2, 2 * H, 2 * W, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(r16(x).double(), w.double()), 2).float() + skip
+    NB, nq = up32(2 * c) // 32, (2 * c) // 4
+    Wm = w[:, :, 0, 0].reshape(nq, 4, c).permute(1, 0, 2).reshape(2 * c, c)
+    xd, Wd, y = dev(nhwc(x)), dev(split16(rowperm_pad(Wm, NB * 32))), dev(nhwc(skip))
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 3, 1, ptr(xd), c, ptr(Wd), 0, None, ptr(y), ptr(y), 2 * c, NB, T, H, W)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), nhwc(ref), 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ network
+def _u8(x):
+    return O.img_as_ubyte(np.clip(x, 0, 1))
+
+
+@pytest.mark.parametrize('path', CASES, ids=[os.path.basename(p)[7:-4] for p in CASES])
+def test_forward_matches_reference_golden(path):
+    z = np.load(path)
+    cfg = NAFNetConfig(**json.loads(str(z['cfg'])))
+    be = backend(cfg, int(z['seed']))
+    y, ref = be.forward(z['input']), z['output']
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    p = O.psnr_f(y, ref)
+    # the goldens' inputs are noisy versions of a synthetic clean image; use the input as the PSNR anchor
+    d = abs(O.psnr_u8(_u8(y), _u8(z['input'])) - O.psnr_u8(_u8(ref), _u8(z['input'])))
+    print(f"{os.path.basename(path)}: PSNR(build, reference) {p:.2f} dB, max abs err {np.abs(y - ref).max():.3e}, |dPSNR_u8| {d:.2e}")
+    assert p >= 58.0, p
+    assert d <= 1e-3, d
+
+
+def test_forward_matches_oracle_256_batch():
+    """Fresh input at 256x256, batch 3 (the per-image statistics of the channel attention must stay per image)."""
+    cfg = NAFNetConfig()
+    be = backend(cfg, 7)
+    sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 7).items()}
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(3, 3, 256, 256, generator=g) * 255).round() / 255
+    x[1] = x[1] * 0.3
+    y = be.forward(x.numpy())
+    with torch.no_grad():
+        ref = nafnet_forward(x, sd, cfg.to_dict()).numpy()
+    p = O.psnr_f(y, ref)
+    print(f"w32 256x256 B=3: PSNR(build, oracle) {p:.2f} dB, max abs err {np.abs(y - ref).max():.3e}")
+    assert p >= 58.0
+    # batch independence: image 1 alone gives bit-identical output
+    y1 = be.forward(x[1:2].numpy())
+    assert np.array_equal(y1[0], y[1])
+
+
+def test_forward_device_nhwc_and_errors():
+    cfg = reduced_nafnet_config()
+    be = backend(cfg, 1)
+    x = torch.rand(2, 3, 20, 24)
+    y = be.forward(x.numpy())
+    xd = nhwc(x).cuda()
+    yd = torch.empty_like(xd)
+    be.forward_device(xd.data_ptr(), 2, 20, 24, yd.data_ptr())
+    assert np.array_equal(yd.cpu().permute(0, 3, 1, 2).numpy(), y)
+    from ira_amd._capi import IraError
+    with pytest.raises(IraError):
+        be.forward(np.zeros((1, 1, 16, 16), np.float32))        # wrong channel count
