@@ -54,8 +54,177 @@ def family_elements(family, C, Hf):
     }.get(family, 0)
 
 
+def nafnet_elements_per_px(cfg):
+    """Fusion contract for NAFNet in the style of SURVEY 8d: per NAFBlock and level-pixel 7c elements
+    (LN+conv1+dw+gate: read c, write c; conv3+residual: read 2c, write c; LN+conv4+gate+conv5+residual: read c, write c),
+    plus the U-Net glue (intro 3+w, ending w+3+3, downs c+2c per source/target pixel, ups 2c+c+c)."""
+    w = cfg.width
+    L = len(cfg.enc_blk_nums)
+    tot = 3 + w + w + 6.0
+    for l in range(L + 1):
+        c = w << l
+        n = cfg.middle_blk_num if l == L else cfg.enc_blk_nums[l] + cfg.dec_blk_nums[L - 1 - l]
+        tot += 7.0 * c * n / 4 ** l
+        if l < L:
+            tot += c / 4 ** l + 2 * c / 4 ** (l + 1)            # down: read c at level l, write 2c at level l+1
+            tot += 2 * c / 4 ** (l + 1) + 2 * c / 4 ** l        # up: read 2c at level l+1, read skip c + write c at level l
+    return tot
+
+
+def nafnet_family_elements(family, c):
+    return {'naf_ln_conv1': 3 * c, 'naf_dw_gate': 3 * c, 'naf_sca_fold': 0, 'naf_conv3_res': 3 * c, 'naf_ln_conv4': 3 * c,
+            'naf_gate_conv5_res': 4 * c}.get(family, 0)
+
+
+def nafnet_macs_per_px(cfg):
+    w, L = cfg.width, len(cfg.enc_blk_nums)
+    tot = 27.0 * w * 2
+    for l in range(L + 1):
+        c = w << l
+        n = cfg.middle_blk_num if l == L else cfg.enc_blk_nums[l] + cfg.dec_blk_nums[L - 1 - l]
+        tot += n * (6.0 * c * c + 18 * c) / 4 ** l
+        if l < L:
+            tot += (8.0 * c * c) / 4 ** (l + 1) + (2 * c) * (4.0 * c) / 4 ** (l + 1)
+    return tot
+
+
+def main_nafnet(args):
+    """BASELINE config 2: NAFNet-width32 denoise, 512x512 RGB tiles, batch 16, one MI355X.  One step = one batch of 16
+    tiles (float32 NHWC, resident in HBM) through the network, output left in HBM.  N > 1: independent replicas, one
+    batch per rank (weak scaling; the path has no exchange step)."""
+    import numpy as np
+    import torch
+    from ira_amd.backend import NAFNetBackend
+    from ira_amd.nafnet import NAFNetConfig, seeded_state_dict
+    from ira_amd.synth import synthetic_noisy_image
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cfg = NAFNetConfig()
+    be = NAFNetBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
+    B, S = args.batch or 16, args.tile
+    _, noisy = synthetic_noisy_image(S, S * 2, 3, sigma=25.0, seed=rank)
+    base = torch.from_numpy(noisy).float().div(255.)
+    x = torch.stack([base[:, (i * 37) % S:(i * 37) % S + S] for i in range(B)]).contiguous().to(dev)     # (B,S,S,3) NHWC
+    y = torch.empty_like(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        be.sync()
+
+    for _ in range(args.warmup):
+        be.forward_device(x.data_ptr(), B, S, S, y.data_ptr())
+    barrier()
+    t0 = time.perf_counter()
+    be.timer_start()
+    for _ in range(args.steps):
+        be.forward_device(x.data_ptr(), B, S, S, y.data_ptr())
+    dev_ms = be.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        be.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    px = B * S * S
+    step_s = elapsed / args.steps
+    value = world * px / 1e6 / step_s
+    net_bytes = nafnet_elements_per_px(cfg) * 2.0 * px
+    flops = nafnet_macs_per_px(cfg) * 2.0 * px
+    result = {
+        'metric': 'restored megapixels/sec (NAFNet-width32 denoise, 512x512 tiles, batch 16)', 'value': round(value, 3), 'unit': 'MP/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic',
+        'config': {'workload': f'NAFNet width 32, enc [2,2,4,8] / middle 12 / dec [2,2,2,2] (29.16M params, seeded weights), '
+                               f'{B} x {S}x{S} RGB float32 tiles per GPU per step', 'tiles_per_s': round(world * B / step_s, 2),
+                   'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
+        'net_roofline': {'bound': 'hbm', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 3),
+                         'achieved': round(net_bytes / 1e9 / step_s, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s per GPU',
+                         'frac': round(net_bytes / 1e9 / step_s / HBM_PEAK_GBS, 4),
+                         'mfma_TFLOPs_per_step_fp32_equiv': round(flops / 1e12, 3),
+                         'mfma_frac_of_dense_f16_peak_incl_hi_lo_planes': round(2 * flops / 1e12 / step_s / MFMA_F16_PEAK_TFLOPS, 4)},
+    }
+    if world == 1 and not args.no_kernel_profile:
+        be.profile_enable(True)
+        be.forward_device(x.data_ptr(), B, S, S, y.data_ptr())
+        prof = be.profile()
+        be.profile_enable(False)
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f, indent=1, sort_keys=True)
+        tot = sum(v['ms'] for v in prof.values())
+        fam_tot = {}
+        for k, v in prof.items():
+            fam_tot[k.split('|')[0]] = fam_tot.get(k.split('|')[0], 0.0) + v['ms']
+        key = max(prof, key=lambda k: prof[k]['ms'])
+        parts = key.split('|')
+        roof = {'bound': 'hbm', 'kernel': key, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
+        if len(parts) == 4:
+            c = int(parts[1][1:])
+            Hh, Ww = (int(v) for v in parts[2].split('x'))
+            T = int(parts[3][1:])
+            alg = nafnet_family_elements(parts[0], c) * 2.0 * T * Hh * Ww
+            avg_ms = prof[key]['ms'] / prof[key]['launches']
+            roof.update({'achieved': round(alg / 1e9 / (avg_ms / 1e3), 1), 'avg_launch_ms': round(avg_ms, 4),
+                         'launches_per_step': prof[key]['launches'], 'algorithmic_bytes_per_launch': int(alg),
+                         'share_of_step': round(prof[key]['ms'] / tot, 4)})
+            roof['frac'] = round(roof['achieved'] / HBM_PEAK_GBS, 4)
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    roof['traffic'] = json.load(open(tpath)).get(key)
+                except Exception:
+                    roof['traffic'] = None
+        result['roofline'] = roof
+        result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
+        result['kernel_ms_total_profiled'] = round(tot, 3)
+    else:
+        result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+                              'traffic': None, 'note': 'per-kernel timing is collected at N=1 only'}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.nafnet_oracle import nafnet_forward
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        xc = x[:1].cpu().permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            nafnet_forward(xc, sd, cfg.to_dict())
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                yc = nafnet_forward(xc, sd, cfg.to_dict())
+            dt = (time.perf_counter() - t1) / reps
+        yg = y[:1].cpu().permute(0, 3, 1, 2).numpy()
+        from oracle.restormer_oracle import psnr_f
+        result['cpu_baseline'] = {
+            'value': round(S * S / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/nafnet_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {S}x{S} tile after '
+                      f'1 warm-up ({dt:.2f} s each); PSNR(GPU tile 0, oracle) = {psnr_f(yg, yc.numpy()):.2f} dB'}
+    print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512'],
+                    help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = BASELINE configs[1]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
@@ -68,6 +237,8 @@ def main():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--profile-out', default='', help='write the per-kernel HIP-event profile (JSON) here')
     args = ap.parse_args()
+    if args.workload == 'nafnet512':
+        return main_nafnet(args)
 
     import numpy as np
     import torch
