@@ -66,12 +66,17 @@ hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int 
 // ---- NAFNet (ira_nafnet.hip).  inmode: 0 fp16, 1 fp16 SimpleGate pair, 2 fp32 space-to-depth (2x2 stride-2 conv), 3 fp32;
 // outmode: 0 plain (+resid), 1 PixelShuffle(2) + add resid at the destination.  (Hg, Wg) = the MFMA pixel grid.
 hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
-                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg);
+                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg,
+                         const float* scale = nullptr);   // inmode 4: fp16 x scaled by scale[t][k] (fp32 [T][K])
 int naf_dw_sg_blocks(int H, int W, int c);      // partial-sum records per image written by launch_naf_dw_sg
 hipError_t launch_naf_dw_sg(hipStream_t st, const void* in, const float* w, const float* bias, void* out, float* part,
                             int T, int H, int W, int c);
-hipError_t launch_naf_sca_fold(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca,
-                               const float* w3, const float* beta, float* s, void* M, int T, int c, int NB);
+hipError_t launch_naf_sca(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca, float* s,
+                          int T, int c);
+// Fused NAFBlock tail (conv3 with the channel attention + residual, LN, conv4, SimpleGate, conv5 + residual), in place on x.
+bool naf_tail_supported(int c);
+hipError_t launch_naf_tail(hipStream_t st, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,
+                           const void* W4, const float* b4, const void* W5, const float* b5, int T, int P);
 hipError_t launch_naf_pad_crop(hipStream_t st, const float* in, float* out, int T, int Hi, int Wi, int Ho, int Wo, int C);
 
 }  // namespace ira

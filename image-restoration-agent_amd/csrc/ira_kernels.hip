@@ -26,6 +26,7 @@
 //      (k = 16s + 8h + j) of a following MFMA that contracts over these channels.
 #include "ira_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace ira {
@@ -359,16 +360,19 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
         const long plane = (f < KS) ? 0 : (long)NB * KS * 512;
         return (const half8*)(W + plane + ((long)nb * KS + (f < KS ? f : f - KS)) * 512 + lane * 8);
     };
+    // blockIdx.y splits the NB row blocks (small pixel counts: more workgroups instead of longer ones)
+    const int nb_per = (NB + gridDim.y - 1) / gridDim.y;
+    const int nb_lo = blockIdx.y * nb_per, nb_hi = min(NB, nb_lo + nb_per);
     half8 stg[SH];
 #pragma unroll
-    for (int i = 0; i < SH; ++i) stg[i] = *gsrc(0, wave + 4 * i);
+    for (int i = 0; i < SH; ++i) stg[i] = *gsrc(nb_lo, wave + 4 * i);
 #pragma unroll
     for (int i = 0; i < SH; ++i) wl[(wave + 4 * i) * 64 + lane] = stg[i];
     __syncthreads();
 
-    for (int nb = 0; nb < NB; ++nb) {
-        const half8* cur = wl + (nb & 1) * F * 64;
-        if (nb + 1 < NB) {
+    for (int nb = nb_lo; nb < nb_hi; ++nb) {
+        const half8* cur = wl + ((nb - nb_lo) & 1) * F * 64;
+        if (nb + 1 < nb_hi) {
 #pragma unroll
             for (int i = 0; i < SH; ++i) stg[i] = *gsrc(nb + 1, wave + 4 * i);     // prefetch, issued before the stores below
         }
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
                 *(half8*)(y + px * y_stride + n0) = o;
             }
         }
-        if (nb + 1 < NB) {
-            half8* nxt = wl + ((nb + 1) & 1) * F * 64;
+        if (nb + 1 < nb_hi) {
+            half8* nxt = wl + ((nb + 1 - nb_lo) & 1) * F * 64;
 #pragma unroll
             for (int i = 0; i < SH; ++i) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
         }
@@ -1153,7 +1157,10 @@ template <int KS>
 static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
                                      f16* y, int ys, int ns, int NB, int T, int P, float eps) {
     const long waves = (long)T * ((P + 31) / 32);
-    const dim3 grid(grid1d(waves, 4)), block(256);
+    const long wgs = (waves + 3) / 4;
+    int splits = 1;
+    if (wgs < 512 && NB >= 8) splits = (int)std::min<long>(NB / 4, (1024 + wgs - 1) / wgs);
+    const dim3 grid(grid1d(waves, 4), splits), block(256);
     const size_t smem = (size_t)2 * 2 * KS * 1024;
 #define IRA_KL(LN_, F32_)                                                                                               \
     do {                                                                                                                \

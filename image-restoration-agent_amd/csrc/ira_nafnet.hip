@@ -6,9 +6,7 @@
 //   t1 = conv1(LN(x))                       k_pw_kres / k_pw_kres_lds  (LN gain/bias folded into W1, eps 1e-6)
 //   g  = SimpleGate(dw3x3(t1)), sum_px g    k_naf_dw_sg                 (per-workgroup partial channel sums)
 //   s  = sca(mean g)                        k_naf_sca                   (AdaptiveAvgPool2d(1) + 1x1, per image)
-//   M  = diag(beta) W3 diag(s)              k_naf_fold                  (the channel attention x*s and the beta scale
-//                                                                        become a per-image matrix, hi/lo planes)
-//   x += M g + beta*b3                      k_naf_pw<.., IN_F16, OUT_RES>
+//   x += (diag(beta) W3)(g * s) + beta*b3   k_naf_pw<.., IN_SCALED, OUT_RES>  (channel attention applied while loading B)
 //   t1 = conv4(LN(x))                       k_pw_kres
 //   x += (diag(gamma) W5)(t1a * t1b) + ..   k_naf_pw<.., IN_GATED, OUT_RES>   (SimpleGate applied while loading B)
 // and the U-Net plumbing: downs (2x2 stride-2 conv, :275-277) = k_naf_pw<.., IN_S2D, OUT_PLAIN> (K = 4c gathered from
@@ -47,7 +45,7 @@ IRA_DEV float wave_sum(float v) {
     return v;
 }
 
-enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3 };
+enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3, IN_SCALED = 4 };
 enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
 
 }  // namespace
@@ -60,12 +58,15 @@ enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
 //   IN_GATED  x: fp16 [T][P][2K], B = x[.., k] * x[.., K + k]                       (SimpleGate :158-161)
 //   IN_S2D    x: fp32 [T][2Hg][2Wg][K/4], k = (dy*2+dx)*(K/4) + ci                  (2x2 stride-2 conv)
 //   IN_F32    x: fp32 [T][P][K]
+//   IN_SCALED x: fp16 [T][P][K], B = x[.., k] * scale[t][k]   (the channel attention x * sca(x), :205, without building a
+//             per-image matrix)
 //   OUT_RES          y fp32 [T][P][N] = acc (+ resid)
 //   OUT_SHUFFLE_ADD  y fp32 [T][2Hg][2Wg][N/4]: row n = q*(N/4) + cc -> sub-pixel q = 2sy+sx, channel cc; + resid there
 template <int NBW, int INMODE, int OUTMODE>
 __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, int K, const f16* __restrict__ W,
                                                 long w_tile_stride, const float* __restrict__ bias, const float* resid,
-                                                float* y, int N, int NBtot, int T, int Hg, int Wg) {
+                                                float* y, int N, int NBtot, int T, int Hg, int Wg,
+                                                const float* __restrict__ scale) {
     constexpr int F = 2 * NBW;
     constexpr int SH = (F + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, in
         half8 b;
         if constexpr (INMODE == IN_F16) {
             b = *(const half8*)((const f16*)xin + px * K + c0);
+        } else if constexpr (INMODE == IN_SCALED) {
+            const half8 a = *(const half8*)((const f16*)xin + px * K + c0);
+            const float* sp = scale + (long)t * K + c0;
+            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[j] = (f16)((float)a[j] * s0[j]); b[4 + j] = (f16)((float)a[4 + j] * s1[j]); }
         } else if constexpr (INMODE == IN_GATED) {
             const f16* src = (const f16*)xin + px * 2 * K + c0;
             const half8 a1 = *(const half8*)src, a2 = *(const half8*)(src + K);
@@ -261,36 +268,39 @@ __global__ __launch_bounds__(256) void k_naf_dw_sg(const f16* __restrict__ in, c
     }
 }
 
-// s[t][o] = sca_b[o] + sum_k sca_w[o][k] * mean_px g[t][.., k]   (:175-179, :205).  grid (T, ceil(c/64)).
-__global__ __launch_bounds__(256) void k_naf_sca(const float* __restrict__ part, int bpt, float inv_px,
-                                                 const float* __restrict__ wsca, const float* __restrict__ bsca,
-                                                 float* __restrict__ s, int c) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // mean[c] + slices[256]
+// s[t][o] = sca_b[o] + sum_k sca_w[o][k] * mean_px g[t][.., k]   (:175-179, :205).  grid (T, ceil(c/64)), 1024 threads.
+// The bpt partial records are summed by 1024/c slices of threads (4 independent accumulators each), then combined in a
+// fixed order: deterministic, and short dependency chains (the first version walked all records serially per channel:
+// 80 us per launch at c = 512).
+__global__ __launch_bounds__(1024) void k_naf_sca(const float* __restrict__ part, int bpt, float inv_px,
+                                                  const float* __restrict__ wsca, const float* __restrict__ bsca,
+                                                  float* __restrict__ s, int c) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // mean[c] + slices[1024 or c]
     float* mean = lds;
     float* sl = lds + c;
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pb = part + (long)t * bpt * c;
-    if (c >= 256) {
-        for (int j = tid; j < c; j += 256) {
-            float a = 0.f;
-            for (int b = 0; b < bpt; ++b) a += pb[(long)b * c + j];
-            mean[j] = a * inv_px;
+    const int nsl = c >= 1024 ? 1 : 1024 / c;                       // c is a power of two
+    for (int j0 = 0; j0 < c; j0 += 1024) {
+        const int j = j0 + tid % (c < 1024 ? c : 1024), sli = c < 1024 ? tid / c : 0;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = sli;
+        for (; b + 3 * nsl < bpt; b += 4 * nsl) {
+            a0 += pb[(long)b * c + j]; a1 += pb[(long)(b + nsl) * c + j];
+            a2 += pb[(long)(b + 2 * nsl) * c + j]; a3 += pb[(long)(b + 3 * nsl) * c + j];
         }
-    } else {
-        const int nsl = 256 / c, j = tid % c, sli = tid / c;    // c divides 256
-        float a = 0.f;
-        for (int b = sli; b < bpt; b += nsl) a += pb[(long)b * c + j];
-        sl[tid] = a;
+        for (; b < bpt; b += nsl) a0 += pb[(long)b * c + j];
+        sl[tid] = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        if (tid < c) {
+        if (tid < c - j0 && tid < 1024) {
             float m = 0.f;
-            for (int k = 0; k < nsl; ++k) m += sl[k * c + tid];
-            mean[tid] = m * inv_px;
+            for (int k = 0; k < nsl; ++k) m += sl[k * (c < 1024 ? c : 1024) + tid];
+            mean[j0 + tid] = m * inv_px;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = 0; i < 16; ++i) {
-        const int o = blockIdx.y * 64 + wave * 16 + i;
+    for (int i = 0; i < 4; ++i) {
+        const int o = blockIdx.y * 64 + wave * 4 + i;
         if (o >= c) break;
         float a = 0.f;
         for (int k = lane; k < c; k += 64) a = fmaf(wsca[(long)o * c + k], mean[k], a);
@@ -299,22 +309,157 @@ __global__ __launch_bounds__(256) void k_naf_sca(const float* __restrict__ part,
     }
 }
 
-// M[t] = diag(beta) W3 diag(s[t]) as fragment-major hi/lo fp16 planes [T][2][NB][c/16][64][8].  grid (T, ceil(c/16)).
-__global__ __launch_bounds__(256) void k_naf_fold(const float* __restrict__ s, const float* __restrict__ w3,
-                                                  const float* __restrict__ beta, f16* __restrict__ M, int c, int NB) {
-    const int t = blockIdx.x, o0 = blockIdx.y * 16, tid = threadIdx.x;
-    const int KT = c >> 4;
-    f16* Mt = M + (long)t * 2 * NB * KT * 512;
-    f16* Ml = Mt + (long)NB * KT * 512;
-    const float* st = s + (long)t * c;
-    for (int idx = tid; idx < 16 * c; idx += 256) {
-        const int o = o0 + idx / c, k = idx % c;
-        if (o >= c) continue;
-        const float a = beta[o] * w3[(long)o * c + k] * st[k];
-        const long off = (((long)(o >> 5) * KT + (k >> 4)) * 64 + 32 * ((k >> 3) & 1) + rowperm(o & 31)) * 8 + (k & 7);
-        const f16 hi = (f16)a;
-        Mt[off] = hi;
-        Ml[off] = (f16)(a - (float)hi);
+// ---------------------------------------------------------------------------------------------
+// Fused NAFBlock tail for C = 32 / 64 (everything after the pooled statistics is per pixel, :205-219):
+//     y = x + (diag(beta) W3)(g * s[t]) + beta*b3
+//     x_out = y + (diag(gamma) W5)( SimpleGate( W4' LN(y) + b4' ) ) + gamma*b5             written in place over x
+// The three unfused kernels moved 3c + 3c + 4c elements per pixel plus the 2c-channel fp16 intermediate; this one reads
+// g (fp16) and x and writes x: 320 B/px at C = 32 instead of 960.  All three weight matrices (hi/lo planes, fragment
+// major) live in LDS for the life of the workgroup (16 KB at C = 32, 64 KB at C = 64) and every wave walks ITER groups
+// of 32 pixels.  The MFMA accumulators never leave registers: D-layout registers are, by construction of rowperm(),
+// the B fragments of the next contraction (see the header of ira_kernels.hip), LayerNorm statistics are a per-lane sum
+// + one cross-half shuffle, and SimpleGate pairs block nb with block NB+nb in the same lane and register.
+constexpr int TAIL_ITER = 8;
+
+template <int C>
+__global__ __launch_bounds__(256) void k_naf_tail(const f16* __restrict__ g, const float* __restrict__ scale, float* x,
+                                                  const f16* __restrict__ W3, const float* __restrict__ b3,
+                                                  const f16* __restrict__ W4, const float* __restrict__ b4,
+                                                  const f16* __restrict__ W5, const float* __restrict__ b5, int T, int P) {
+    constexpr int NB = C / 32, KS = C / 16;
+    constexpr int F3 = 2 * NB * KS, F4 = 2 * 2 * NB * KS;           // fragments (1 KB) of W3 / W5 and of W4
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* w3 = (half8*)smem;                 // [2][NB][KS][64]
+    half8* w4 = w3 + F3 * 64;                 // [2][2NB][KS][64]
+    half8* w5 = w4 + F4 * 64;                 // [2][NB][KS][64]
+    float* bl = (float*)(w5 + F3 * 64);       // b3[C] b4[2C] b5[C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < F3 * 64; i += 256) { w3[i] = ((const half8*)W3)[i]; w5[i] = ((const half8*)W5)[i]; }
+    for (int i = tid; i < F4 * 64; i += 256) w4[i] = ((const half8*)W4)[i];
+    for (int i = tid; i < C; i += 256) { bl[i] = b3[i]; bl[3 * C + i] = b5[i]; }
+    for (int i = tid; i < 2 * C; i += 256) bl[C + i] = b4[i];
+    __syncthreads();
+
+    const int chunks = (P + 31) >> 5;
+    const int wg_per_tile = (chunks + 4 * TAIL_ITER - 1) / (4 * TAIL_ITER);
+    const long bid = xcd_swz(blockIdx.x, gridDim.x);
+    const int t = (int)(bid / wg_per_tile);
+    const int ch0 = (int)(bid % wg_per_tile) * 4 * TAIL_ITER + wave * TAIL_ITER;
+    const float* sc = scale + (long)t * C;
+    f32x4 sv[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { sv[s][0] = *(const f32x4*)(sc + 16 * s + 8 * h); sv[s][1] = *(const f32x4*)(sc + 16 * s + 8 * h + 4); }
+
+    for (int it = 0; it < TAIL_ITER; ++it) {
+        const int ch = ch0 + it;
+        if (ch >= chunks) break;
+        const int p = ch * 32 + r;
+        const bool valid = p < P;
+        const long px = (long)t * P + (valid ? p : P - 1);
+        // B fragments of conv3: g * s
+        half8 b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const half8 a = *(const half8*)(g + px * C + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[s][j] = (f16)((float)a[j] * sv[s][0][j]); b[s][4 + j] = (f16)((float)a[4 + j] * sv[s][1][j]); }
+        }
+        // y = x + b3 + W3 (g*s)
+        f32x16 y[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 32 * nb + 16 * u + 8 * h;
+                const f32x4 xl = *(const f32x4*)(x + px * C + n0), xh = *(const f32x4*)(x + px * C + n0 + 4);
+                const f32x4 bl0 = *(const f32x4*)(bl + n0), bl1 = *(const f32x4*)(bl + n0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { y[nb][8 * u + j] = xl[j] + bl0[j]; y[nb][8 * u + 4 + j] = xh[j] + bl1[j]; }
+            }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                y[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3[((0 * NB + nb) * KS + s) * 64 + lane], b[s], y[nb], 0, 0, 0);
+                y[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3[((1 * NB + nb) * KS + s) * 64 + lane], b[s], y[nb], 0, 0, 0);
+            }
+        // LayerNorm2d statistics over the C channels of the pixel (lane pair r, r+32)
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += y[nb][j];
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float d = y[nb][j] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-6f);
+        // register (nb, 8u + j) = channel 32nb + 16u + 8h + j = element j of the B fragment of k-step 2nb + u
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[2 * nb + u][j] = (f16)((y[nb][8 * u + j] - mu) * rstd);
+        // out = y + b5 + W5 gate(W4 n + b4)
+        f32x16 o[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 3 * C + 32 * nb + 16 * u + 8 * h;
+                const f32x4 bl0 = *(const f32x4*)(bl + n0), bl1 = *(const f32x4*)(bl + n0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[nb][8 * u + j] = y[nb][8 * u + j] + bl0[j]; o[nb][8 * u + 4 + j] = y[nb][8 * u + 4 + j] + bl1[j]; }
+            }
+#pragma unroll
+        for (int pr = 0; pr < NB; ++pr) {
+            f32x16 a1, a2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n1 = C + 32 * pr + 16 * u + 8 * h, n2 = n1 + C;
+                const f32x4 p0 = *(const f32x4*)(bl + n1), p1 = *(const f32x4*)(bl + n1 + 4);
+                const f32x4 q0 = *(const f32x4*)(bl + n2), q1 = *(const f32x4*)(bl + n2 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a1[8 * u + j] = p0[j]; a1[8 * u + 4 + j] = p1[j]; a2[8 * u + j] = q0[j]; a2[8 * u + 4 + j] = q1[j]; }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[((0 * 2 * NB + pr) * KS + s) * 64 + lane], b[s], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[((1 * 2 * NB + pr) * KS + s) * 64 + lane], b[s], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[((0 * 2 * NB + NB + pr) * KS + s) * 64 + lane], b[s], a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[((1 * 2 * NB + NB + pr) * KS + s) * 64 + lane], b[s], a2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                half8 gf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gf[j] = (f16)(a1[8 * u + j] * a2[8 * u + j]);
+                const int s5 = 2 * pr + u;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w5[((0 * NB + nb) * KS + s5) * 64 + lane], gf, o[nb], 0, 0, 0);
+                    o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w5[((1 * NB + nb) * KS + s5) * 64 + lane], gf, o[nb], 0, 0, 0);
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n0 = 32 * nb + 16 * u + 8 * h;
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { lo[j] = o[nb][8 * u + j]; hi[j] = o[nb][8 * u + 4 + j]; }
+                    *(f32x4*)(x + px * C + n0) = lo;
+                    *(f32x4*)(x + px * C + n0 + 4) = hi;
+                }
+        }
     }
 }
 
@@ -335,36 +480,39 @@ __global__ __launch_bounds__(256) void k_naf_pad_crop(const float* __restrict__ 
 // =============================================================================================
 template <int NBW, int INMODE, int OUTMODE>
 static hipError_t naf_pw_launch(hipStream_t st, const void* x, int K, const f16* W, long wts, const float* bias,
-                                const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+                                const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg, const float* scale) {
     const int chunks = (Hg * Wg + 31) / 32;
     const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4)), (unsigned)(NBtot / NBW)), block(256);
     const size_t smem = (size_t)2 * 2 * NBW * 1024;
-    hipLaunchKernelGGL((k_naf_pw<NBW, INMODE, OUTMODE>), grid, block, smem, st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+    hipLaunchKernelGGL((k_naf_pw<NBW, INMODE, OUTMODE>), grid, block, smem, st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
     return hipGetLastError();
 }
 
 template <int INMODE, int OUTMODE>
 static hipError_t naf_pw_nbw(hipStream_t st, const void* x, int K, const f16* W, long wts, const float* bias,
-                             const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
-    if (NBtot % 8 == 0) return naf_pw_launch<8, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
-    if (NBtot % 4 == 0) return naf_pw_launch<4, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
-    if (NBtot % 2 == 0) return naf_pw_launch<2, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
-    return naf_pw_launch<1, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg);
+                             const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg, const float* scale) {
+    if (NBtot % 8 == 0) return naf_pw_launch<8, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
+    if (NBtot % 4 == 0) return naf_pw_launch<4, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
+    if (NBtot % 2 == 0) return naf_pw_launch<2, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
+    return naf_pw_launch<1, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
 }
 
 hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
-                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
+                         const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg,
+                         const float* scale) {
+    if (inmode == IN_SCALED && scale == nullptr) return hipErrorInvalidValue;
     if (K <= 0 || K % 16 != 0 || N % 8 != 0 || NBtot * 32 < N || T <= 0 || Hg <= 0 || Wg <= 0) return hipErrorInvalidValue;
     if (inmode == IN_S2D && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
     if (outmode == OUT_SHUFFLE_ADD && (N % 32 != 0)) return hipErrorInvalidValue;  // N/4 channels, runs of 8
     const f16* Wh = (const f16*)W;
-#define IRA_NAF(IM, OM) return naf_pw_nbw<IM, OM>(st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg)
+#define IRA_NAF(IM, OM) return naf_pw_nbw<IM, OM>(st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg, scale)
     if (outmode == OUT_RES) {
         switch (inmode) {
             case IN_F16: IRA_NAF(IN_F16, OUT_RES);
             case IN_GATED: IRA_NAF(IN_GATED, OUT_RES);
             case IN_S2D: IRA_NAF(IN_S2D, OUT_RES);
             case IN_F32: IRA_NAF(IN_F32, OUT_RES);
+            case IN_SCALED: IRA_NAF(IN_SCALED, OUT_RES);
             default: return hipErrorInvalidValue;
         }
     } else if (outmode == OUT_SHUFFLE_ADD && inmode == IN_F32) {
@@ -388,14 +536,38 @@ hipError_t launch_naf_dw_sg(hipStream_t st, const void* in, const float* w, cons
     return hipGetLastError();
 }
 
-hipError_t launch_naf_sca_fold(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca,
-                               const float* w3, const float* beta, float* s, void* M, int T, int c, int NB) {
-    if (c < 16 || (c & (c - 1)) != 0 || c > 2048 || NB * 32 < c) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_naf_sca, dim3(T, (c + 63) / 64), dim3(256), (size_t)(c + 256) * sizeof(float), st, part, bpt,
+bool naf_tail_supported(int c) { return c == 32 || c == 64; }
+
+template <int C>
+static hipError_t naf_tail_launch(hipStream_t st, const void* g, const float* scale, float* x, const void* W3, const float* b3,
+                                  const void* W4, const float* b4, const void* W5, const float* b5, int T, int P) {
+    constexpr int NB = C / 32, KS = C / 16;
+    const size_t smem = (size_t)(2 * (2 * NB * KS) + 4 * NB * KS) * 1024 + (size_t)4 * C * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_naf_tail<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const int chunks = (P + 31) / 32;
+    const int wg_per_tile = (chunks + 4 * TAIL_ITER - 1) / (4 * TAIL_ITER);
+    hipLaunchKernelGGL((k_naf_tail<C>), dim3((unsigned)((long)T * wg_per_tile)), dim3(256), smem, st, (const f16*)g, scale, x,
+                       (const f16*)W3, b3, (const f16*)W4, b4, (const f16*)W5, b5, T, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_naf_tail(hipStream_t st, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,
+                           const void* W4, const float* b4, const void* W5, const float* b5, int T, int P) {
+    if (c == 32) return naf_tail_launch<32>(st, g, scale, x, W3, b3, W4, b4, W5, b5, T, P);
+    if (c == 64) return naf_tail_launch<64>(st, g, scale, x, W3, b3, W4, b4, W5, b5, T, P);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_naf_sca(hipStream_t st, const float* part, int bpt, long npx, const float* wsca, const float* bsca, float* s,
+                          int T, int c) {
+    if (c < 16 || (c & (c - 1)) != 0 || c > 2048) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_naf_sca, dim3(T, (c + 63) / 64), dim3(1024), (size_t)(c + 1024) * sizeof(float), st, part, bpt,
                        1.0f / (float)npx, wsca, bsca, s, c);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_naf_fold, dim3(T, (c + 15) / 16), dim3(256), 0, st, s, w3, beta, (f16*)M, c, NB);
     return hipGetLastError();
 }
 

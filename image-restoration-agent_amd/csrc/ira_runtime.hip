@@ -34,7 +34,7 @@ struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into th
     const void* c1_w = nullptr;  const float* c1_b = nullptr;     // conv1 with norm1 folded in
     const float* dw_w = nullptr; const float* dw_b = nullptr;     // conv2 (depthwise 3x3)
     const float* sca_w = nullptr; const float* sca_b = nullptr;   // sca.1
-    const float* c3_w = nullptr; const float* beta = nullptr; const float* c3_b = nullptr;   // conv3 fp32 (folded per image), beta*b3
+    const void* c3_w = nullptr; const float* c3_b = nullptr;    // diag(beta) conv3, beta*b3 (the SCA scale is applied to its input)
     const void* c4_w = nullptr;  const float* c4_b = nullptr;     // conv4 with norm2 folded in
     const void* c5_w = nullptr;  const float* c5_b = nullptr;     // diag(gamma) conv5, gamma*b5
 };
@@ -399,8 +399,7 @@ bool naf_load_block(ira_model* m, const std::string& p, int c, NBlk& b) {
     b.dw_b = (const float*)wptr(m, p + ".dw_b", true, (size_t)2 * c * 4);
     b.sca_w = (const float*)wptr(m, p + ".sca_w", true, (size_t)c * c * 4);
     b.sca_b = (const float*)wptr(m, p + ".sca_b", true, (size_t)c * 4);
-    b.c3_w = (const float*)wptr(m, p + ".c3_w", true, (size_t)c * c * 4);
-    b.beta = (const float*)wptr(m, p + ".beta", true, (size_t)c * 4);
+    b.c3_w = wptr(m, p + ".c3_w", true, 2 * NBc * c * 2);
     b.c3_b = (const float*)wptr(m, p + ".c3_b", true, NBc * 4);
     b.c4_w = wptr(m, p + ".c4_w", true, 2 * NB2 * c * 2);
     b.c4_b = (const float*)wptr(m, p + ".c4_b", true, NB2 * 4);
@@ -454,17 +453,16 @@ int naf_ensure_workspace(ira_model* m, int T, int H, int W) {
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     const size_t t = (size_t)T;
     std::vector<size_t> o_x(L + 1);
-    size_t mt1 = 0, mg = 0, mpart = 0, mM = 0, ms = 0;
+    size_t mt1 = 0, mg = 0, mpart = 0, ms = 0;
     for (int l = 0; l <= L; ++l) {
         const size_t ch = (size_t)c.width << l, P = (size_t)(H >> l) * (W >> l);
         o_x[l] = take(t * P * ch * 4);
         mt1 = std::max(mt1, t * P * 2 * ch * 2);
         mg = std::max(mg, t * P * ch * 2);
         mpart = std::max(mpart, t * (size_t)ira::naf_dw_sg_blocks(H >> l, W >> l, (int)ch) * ch * 4);
-        mM = std::max(mM, t * 2 * up32((int)ch) * ch * 2);
         ms = std::max(ms, t * ch * 4);
     }
-    const size_t o_t1 = take(mt1), o_g = take(mg), o_p = take(mpart), o_M = take(mM), o_s = take(ms);
+    const size_t o_t1 = take(mt1), o_g = take(mg), o_p = take(mpart), o_s = take(ms);
     const size_t o_pi = take(t * H * W * c.img_channel * 4), o_po = take(t * H * W * c.img_channel * 4);
     hipError_t e = hipMalloc((void**)&m->ws, off);
     if (e != hipSuccess) {
@@ -475,9 +473,8 @@ int naf_ensure_workspace(ira_model* m, int T, int H, int W) {
     char* b = m->ws;
     m->nx.resize(L + 1);
     for (int l = 0; l <= L; ++l) m->nx[l] = (float*)(b + o_x[l]);
-    m->hp = b + o_t1; m->g = b + o_g; m->part = (float*)(b + o_p); m->M = b + o_M; m->nsca = (float*)(b + o_s);
+    m->hp = b + o_t1; m->g = b + o_g; m->part = (float*)(b + o_p); m->nsca = (float*)(b + o_s);
     m->npad_in = (float*)(b + o_pi); m->npad_out = (float*)(b + o_po);
-    HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));      // rows >= c of a 32-row block are MFMA padding
     return IRA_OK;
 }
 
@@ -486,7 +483,7 @@ int naf_run_block(ira_model* m, const NBlk& b, float* x, int T, int H, int W, in
     const int P = H * W, NBc = up32(c) / 32, NB2 = up32(2 * c) / 32;
     char k_[6][64];
     if (m->profile) {
-        const char* fam[6] = {"naf_ln_conv1", "naf_dw_gate", "naf_sca_fold", "naf_conv3_res", "naf_ln_conv4", "naf_gate_conv5_res"};
+        const char* fam[6] = {"naf_ln_conv1", "naf_dw_gate", "naf_sca", "naf_conv3_res", "naf_ln_conv4", "naf_gate_conv5_res"};
         for (int i = 0; i < 6; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], c, H, W, T);
     } else {
         for (int i = 0; i < 6; ++i) k_[i][0] = 0;
@@ -495,8 +492,14 @@ int naf_run_block(ira_model* m, const NBlk& b, float* x, int T, int H, int W, in
     const int bpt = ira::naf_dw_sg_blocks(H, W, c);
     RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, c, b.c1_w, b.c1_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
     RUN(m, k_[1], ira::launch_naf_dw_sg(st, m->hp, b.dw_w, b.dw_b, m->g, m->part, T, H, W, c));
-    RUN(m, k_[2], ira::launch_naf_sca_fold(st, m->part, bpt, (long)P, b.sca_w, b.sca_b, b.c3_w, b.beta, m->nsca, m->M, T, c, NBc));
-    RUN(m, k_[3], ira::launch_naf_pw(st, 0, 0, m->g, c, m->M, 2L * NBc * 32 * c, b.c3_b, x, x, c, NBc, T, H, W));
+    RUN(m, k_[2], ira::launch_naf_sca(st, m->part, bpt, (long)P, b.sca_w, b.sca_b, m->nsca, T, c));
+    if (m->use_fused_ffn && ira::naf_tail_supported(c)) {
+        char kt[64];
+        if (m->profile) snprintf(kt, sizeof kt, "naf_tail_fused|C%d|%dx%d|T%d", c, H, W, T); else kt[0] = 0;
+        RUN(m, kt, ira::launch_naf_tail(st, m->g, m->nsca, x, c, b.c3_w, b.c3_b, b.c4_w, b.c4_b, b.c5_w, b.c5_b, T, P));
+        return IRA_OK;
+    }
+    RUN(m, k_[3], ira::launch_naf_pw(st, 4, 0, m->g, c, b.c3_w, 0, b.c3_b, x, x, c, NBc, T, H, W, m->nsca));
     RUN(m, k_[4], ira::launch_pw_kres(st, x, true, 2, c, b.c4_w, b.c4_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
     RUN(m, k_[5], ira::launch_naf_pw(st, 1, 0, m->hp, c, b.c5_w, 0, b.c5_b, x, x, c, NBc, T, H, W));
     return IRA_OK;
@@ -990,8 +993,8 @@ int ira_op_concat2(ira_model_t* m, const float* a, int Ca, const float* b, int C
 }
 
 int ira_op_naf_pw(ira_model_t* m, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
-                  const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg) {
-    OP_BODY(m, "op", ira::launch_naf_pw(m->st, inmode, outmode, x, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg));
+                  const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg, const float* scale) {
+    OP_BODY(m, "op", ira::launch_naf_pw(m->st, inmode, outmode, x, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg, scale));
 }
 
 int ira_op_naf_dw_sg(ira_model_t* m, const void* in, const float* w, const float* bias, void* out, float* part, int T, int H,
@@ -1000,9 +1003,14 @@ int ira_op_naf_dw_sg(ira_model_t* m, const void* in, const float* w, const float
     OP_BODY(m, "op", ira::launch_naf_dw_sg(m->st, in, w, bias, out, part, T, H, W, c));
 }
 
-int ira_op_naf_sca_fold(ira_model_t* m, const float* part, int blocks_per_image, long npx, const float* wsca, const float* bsca,
-                        const float* w3, const float* beta, float* s, void* M, int T, int c, int NB) {
-    OP_BODY(m, "op", ira::launch_naf_sca_fold(m->st, part, blocks_per_image, npx, wsca, bsca, w3, beta, s, M, T, c, NB));
+int ira_op_naf_tail(ira_model_t* m, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,
+                    const void* W4, const float* b4, const void* W5, const float* b5, int T, int P) {
+    OP_BODY(m, "op", ira::launch_naf_tail(m->st, g, scale, x, c, W3, b3, W4, b4, W5, b5, T, P));
+}
+
+int ira_op_naf_sca(ira_model_t* m, const float* part, int blocks_per_image, long npx, const float* wsca, const float* bsca,
+                   float* s, int T, int c) {
+    OP_BODY(m, "op", ira::launch_naf_sca(m->st, part, blocks_per_image, npx, wsca, bsca, s, T, c));
 }
 
 }  // extern "C"

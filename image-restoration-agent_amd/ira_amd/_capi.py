@@ -72,9 +72,10 @@ SIGNATURES = {
     'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     'ira_op_concat2': (_i, [_vp, _vp, _i, _vp, _i, _vp, _l]),
     'ira_op_pw_kres_eps': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float]),
-    'ira_op_naf_pw': (_i, [_vp, _i, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    'ira_op_naf_pw': (_i, [_vp, _i, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ira_op_naf_dw_sg': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _pi]),
-    'ira_op_naf_sca_fold': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    'ira_op_naf_tail': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
+    'ira_op_naf_sca': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i]),
 }
 
 _lib = None

@@ -100,8 +100,7 @@ def nafnet_cfg_struct(cfg: NAFNetConfig):
 
 def pack_nafnet_block(sd, p: str, c: int, out: dict, name: str):
     """One NAFBlock (NAFNet_arch.py:163-219).  Folds: LayerNorm2d gain/bias into conv1 / conv4
-    (conv(g*n + b) = (W diag g) n + (W b + bias)); beta into conv3's bias (its weight is folded per image on the
-    device together with the channel attention); gamma into conv5."""
+    (conv(g*n + b) = (W diag g) n + (W b + bias)); beta into conv3 and gamma into conv5 (weights and biases)."""
     from .pack import frag_major, split16, up32, _np, _pad_rows, _dw_pack
     f64 = lambda k: _np(sd[f'{p}.{k}']).astype(np.float64)
     for norm, conv, dst in (('norm1', 'conv1', 'c1'), ('norm2', 'conv4', 'c4')):
@@ -113,8 +112,7 @@ def pack_nafnet_block(sd, p: str, c: int, out: dict, name: str):
     out[f'{name}.sca_w'] = np.ascontiguousarray(_np(sd[f'{p}.sca.1.weight'])[:, :, 0, 0])
     out[f'{name}.sca_b'] = _np(sd[f'{p}.sca.1.bias']).astype(np.float32)
     beta, gamma = f64('beta').reshape(-1), f64('gamma').reshape(-1)
-    out[f'{name}.c3_w'] = np.ascontiguousarray(_np(sd[f'{p}.conv3.weight'])[:, :, 0, 0])
-    out[f'{name}.beta'] = beta.astype(np.float32)
+    out[f'{name}.c3_w'] = frag_major(split16(_pad_rows(beta[:, None] * f64('conv3.weight')[:, :, 0, 0], up32(c))))
     out[f'{name}.c3_b'] = _pad_rows((beta * f64('conv3.bias')).astype(np.float32), up32(c))
     out[f'{name}.c5_w'] = frag_major(split16(_pad_rows(gamma[:, None] * f64('conv5.weight')[:, :, 0, 0], up32(c))))
     out[f'{name}.c5_b'] = _pad_rows((gamma * f64('conv5.bias')).astype(np.float32), up32(c))

@@ -233,22 +233,28 @@ int ira_op_pw_kres_eps(ira_model_t* m, const void* x_dev, int in_f32, int ln_mod
  * ([2 planes][NBtot][K/16][64][8], per image if w_tile_stride != 0), fp32 result.
  * inmode 0: x fp16 (T,Hg,Wg,K).  1: x fp16 (T,Hg,Wg,2K), operand = x[..,:K]*x[..,K:] (SimpleGate :158-161).
  *        2: x fp32 (T,2Hg,2Wg,K/4), k = (dy*2+dx)*(K/4)+ci: the 2x2 stride-2 "downs" conv (:275-277).  3: x fp32 (T,Hg,Wg,K).
+ *        4: x fp16 (T,Hg,Wg,K), operand = x * scale[t] (scale fp32 [T][K]): the channel attention x * sca(x) (:205).
  * outmode 0: y (T,Hg,Wg,N) = acc + bias (+ resid).  1: y (T,2Hg,2Wg,N/4), row n = (2sy+sx)*(N/4)+cc goes to sub-pixel
  *        (sy,sx) channel cc (PixelShuffle(2), :286-291, rows permuted by the packer), + resid (the encoder skip, :320). */
 int ira_op_naf_pw(ira_model_t* m, int inmode, int outmode, const void* x_dev, int K, const void* W_f16_dev,
                   long w_tile_stride, const float* bias_dev, const float* resid_dev, float* y_dev, int N, int NBtot,
-                  int T, int Hg, int Wg);
+                  int T, int Hg, int Wg, const float* scale_dev);
 
 /* conv2 (depthwise 3x3, bias) + SimpleGate + partial channel sums for the global average pool (:202-205):
  * in fp16 (T,H,W,2c), w fp32 [9][2c], out fp16 (T,H,W,c), part fp32 [T][blocks_per_image][c] (returned count). */
 int ira_op_naf_dw_sg(ira_model_t* m, const void* in_dev, const float* w_dev, const float* bias_dev, void* out_dev,
                      float* part_dev, int T, int H, int W, int c, int* blocks_per_image);
 
-/* s[t] = sca_w . mean_px(g[t]) + sca_b (:175-179);  M[t] = diag(beta) W3 diag(s[t]) packed hi/lo fragment-major
- * [T][2][NB][c/16][64][8] (the channel attention and the beta scale folded into conv3, :205-211). */
-int ira_op_naf_sca_fold(ira_model_t* m, const float* part_dev, int blocks_per_image, long npx, const float* wsca_dev,
-                        const float* bsca_dev, const float* w3_dev, const float* beta_dev, float* s_dev, void* M_f16_dev,
-                        int T, int c, int NB);
+/* Fused NAFBlock tail, in place on x (fp32 (T,P,c), c in {32, 64}):  y = x + W3'(g * s[t]) + b3';
+ * x = y + W5'(SimpleGate(W4' LN2d(y) + b4')) + b5'  (:205-219; W3' = diag(beta) conv3, W4' = conv4 diag(norm2 gain),
+ * W5' = diag(gamma) conv5, packed hi/lo fragment-major; b* fp32, padded to 32).  g fp16 (T,P,c), s fp32 [T][c]. */
+int ira_op_naf_tail(ira_model_t* m, const void* g_dev, const float* s_dev, float* x_dev, int c, const void* W3_dev,
+                    const float* b3_dev, const void* W4_dev, const float* b4_dev, const void* W5_dev, const float* b5_dev,
+                    int T, int P);
+
+/* s[t] = sca_w . mean_px(g[t]) + sca_b: AdaptiveAvgPool2d(1) + 1x1 conv per image (:175-179); s fp32 [T][c]. */
+int ira_op_naf_sca(ira_model_t* m, const float* part_dev, int blocks_per_image, long npx, const float* wsca_dev,
+                   const float* bsca_dev, float* s_dev, int T, int c);
 
 #ifdef __cplusplus
 }

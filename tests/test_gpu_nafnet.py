@@ -89,30 +89,18 @@ def test_dw_simplegate_pool(ctx, c, T, H, W):
 
 
 @pytest.mark.parametrize('c,T,bpt', [(16, 2, 3), (32, 3, 1024), (128, 1, 7), (512, 2, 5)])
-def test_sca_fold(ctx, c, T, bpt):
-    """sca (mean -> 1x1, :175-179) and M = diag(beta) conv3 diag(s) (:205-211) in the packed hi/lo layout."""
-    from ira_amd.pack import frag_major, split16 as s16
+def test_sca(ctx, c, T, bpt):
+    """sca: AdaptiveAvgPool2d(1) from the partial sums + 1x1 conv (:175-179), per image."""
     g = torch.Generator().manual_seed(c + bpt)
     part = torch.randn(T, bpt, c, generator=g)
     npx = 1000
     wsca, bsca = torch.randn(c, c, generator=g) / c ** 0.5, torch.randn(c, generator=g) * 0.1
-    w3, beta = torch.randn(c, c, generator=g) / c ** 0.5, torch.randn(c, generator=g)
-    mean = part.double().sum(1) / npx
-    s = mean @ wsca.double().t() + bsca.double()
-    NB = up32(c) // 32
+    s = (part.double().sum(1) / npx) @ wsca.double().t() + bsca.double()
     sd = torch.full((T, c), float('nan')).cuda()
-    M = torch.zeros(T, 2, NB, c // 16, 64, 8, dtype=torch.float16).cuda()
-    pd, a, b_, c_, d_ = dev(part), dev(wsca), dev(bsca), dev(w3), dev(beta)
-    rc = ctx._lib.ira_op_naf_sca_fold(ctx.handle, ptr(pd), bpt, npx, ptr(a), ptr(b_), ptr(c_), ptr(d_), ptr(sd), ptr(M), T, c, NB)
+    pd, a, b_ = dev(part), dev(wsca), dev(bsca)
+    rc = ctx._lib.ira_op_naf_sca(ctx.handle, ptr(pd), bpt, npx, ptr(a), ptr(b_), ptr(sd), T, c)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(sd.cpu(), s.float(), 2e-5, atol_scale=1e-5)
-    for t in range(T):
-        Mref = beta.double()[:, None] * w3.double() * sd.cpu().double()[t][None, :]
-        Mp = np.zeros((NB * 32, c)); Mp[:c] = Mref.numpy()
-        want = frag_major(s16(Mp)).astype(np.float64)                 # [2][NB][c/16][64][8]
-        got = M[t].cpu().double().numpy()
-        np.testing.assert_allclose(got[0] + got[1], want[0] + want[1], rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(got[0], want[0], rtol=2e-3, atol=1e-6)
 
 
 def _pw_ref(xb, Wm, bias, N):
@@ -133,7 +121,24 @@ def test_pw_f16_residual(ctx, c, T, H, W, per_image):
     Wd = dev(torch.stack([split16(rowperm_pad(Wm[i], NB * 32)) for i in range(Wm.shape[0])]))
     xd, bd, y = dev(x.half()), dev(bias), dev(res)
     rc = ctx._lib.ira_op_naf_pw(ctx.handle, 0, 0, ptr(xd), c, ptr(Wd), 2 * NB * 32 * c if per_image else 0, ptr(bd), ptr(y), ptr(y),
-                                c, NB, T, H, W)
+                                c, NB, T, H, W, None)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(y.cpu(), ref, 2e-5)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(16, 2, 5, 7), (32, 3, 9, 9), (128, 2, 6, 6), (512, 2, 5, 5)])
+def test_pw_scaled_residual(ctx, c, T, H, W):
+    """x += (diag(beta) conv3)(g * sca) + beta*b3 (:205-211): the per-image channel scale is applied to the B operand."""
+    g = torch.Generator().manual_seed(c * 13 + H)
+    P, NB = H * W, up32(c) // 32
+    x = r16(torch.randn(T, P, c, generator=g))
+    sc = torch.randn(T, c, generator=g) * 0.5 + 1.0
+    Wm = torch.randn(c, c, generator=g) / c ** 0.5
+    bias = rowperm_pad(torch.randn(c, 1, generator=g) * 0.1, NB * 32)[:, 0]
+    res = torch.randn(T, P, c, generator=g)
+    ref = torch.stack([_pw_ref(x[t] * sc[t][None, :], Wm, bias, c) for t in range(T)]) + res
+    xd, Wd, bd, y, sd = dev(x.half()), dev(split16(rowperm_pad(Wm, NB * 32))), dev(bias), dev(res), dev(sc)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 4, 0, ptr(xd), c, ptr(Wd), 0, ptr(bd), ptr(y), ptr(y), c, NB, T, H, W, ptr(sd))
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(y.cpu(), ref, 2e-5)
 
@@ -149,9 +154,33 @@ def test_pw_gated_residual(ctx, c, T, H, W):
     res = torch.randn(T * P, c, generator=g)
     ref = _pw_ref(t2[:, :c] * t2[:, c:], Wm, bias, c) + res
     td, Wd, bd, y = dev(t2.half()), dev(split16(rowperm_pad(Wm, NB * 32))), dev(bias), dev(res)
-    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 1, 0, ptr(td), c, ptr(Wd), 0, ptr(bd), ptr(y), ptr(y), c, NB, T, H, W)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 1, 0, ptr(td), c, ptr(Wd), 0, ptr(bd), ptr(y), ptr(y), c, NB, T, H, W, None)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(y.cpu(), ref, 2e-5)
+
+
+@pytest.mark.parametrize('c,T,H,W', [(32, 2, 9, 11), (64, 3, 8, 8), (32, 1, 40, 40), (64, 1, 33, 7)])
+def test_tail_fused(ctx, c, T, H, W):
+    """The fused NAFBlock tail (:205-219) against the same chain written with torch ops, same fp16 roundings."""
+    g_ = torch.Generator().manual_seed(c * 17 + H)
+    P, NB, NB2 = H * W, up32(c) // 32, up32(2 * c) // 32
+    gt = r16(torch.randn(T, P, c, generator=g_))
+    sc = torch.randn(T, c, generator=g_) * 0.5 + 1.0
+    x = torch.randn(T, P, c, generator=g_) * 1.5
+    W3, W4, W5 = (torch.randn(n, c, generator=g_) / c ** 0.5 for n in (c, 2 * c, c))
+    b3, b4, b5 = (torch.randn(n, generator=g_) * 0.1 for n in (c, 2 * c, c))
+    y = x.double() + torch.einsum('tpk,nk->tpn', r16(gt * sc[:, None, :]).double(), W3.double()) + b3.double()
+    mu = y.mean(-1, keepdim=True)
+    n = (y - mu) / torch.sqrt(y.var(-1, keepdim=True, unbiased=False) + 1e-6)
+    t4 = torch.einsum('tpk,nk->tpn', r16(n.float()).double(), W4.double()) + b4.double()
+    gg = r16((t4[..., :c] * t4[..., c:]).float()).double()
+    ref = (y + torch.einsum('tpk,nk->tpn', gg, W5.double()) + b5.double()).float()
+    gd, sd, xd = dev(gt.half()), dev(sc), dev(x)
+    W3d, W4d, W5d = dev(split16(rowperm_pad(W3, NB * 32))), dev(split16(rowperm_pad(W4, NB2 * 32))), dev(split16(rowperm_pad(W5, NB * 32)))
+    b3d, b4d, b5d = dev(b3), dev(b4), dev(b5)
+    rc = ctx._lib.ira_op_naf_tail(ctx.handle, ptr(gd), ptr(sd), ptr(xd), c, ptr(W3d), ptr(b3d), ptr(W4d), ptr(b4d), ptr(W5d), ptr(b5d), T, P)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    close(xd.cpu(), ref, 5e-4, atol_scale=3e-4)
 
 
 @pytest.mark.parametrize('c,T,H,W', [(16, 2, 6, 10), (32, 1, 16, 16), (256, 1, 4, 6)])
@@ -166,7 +195,7 @@ def test_down_conv2x2(ctx, c, T, H, W):
     Wm = w.permute(0, 2, 3, 1).reshape(2 * c, 4 * c)
     xd, Wd, bd = dev(nhwc(x)), dev(split16(rowperm_pad(Wm, NB * 32))), dev(rowperm_pad(b[:, None], NB * 32)[:, 0])
     y = torch.full((T, H // 2, W // 2, 2 * c), float('nan')).cuda()
-    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 2, 0, ptr(xd), 4 * c, ptr(Wd), 0, ptr(bd), None, ptr(y), 2 * c, NB, T, H // 2, W // 2)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 2, 0, ptr(xd), 4 * c, ptr(Wd), 0, ptr(bd), None, ptr(y), 2 * c, NB, T, H // 2, W // 2, None)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(y.cpu(), nhwc(ref), 2e-5)
 
@@ -182,7 +211,7 @@ def test_up_shuffle_add(ctx, c, T, H, W):
     NB, nq = up32(2 * c) // 32, (2 * c) // 4
     Wm = w[:, :, 0, 0].reshape(nq, 4, c).permute(1, 0, 2).reshape(2 * c, c)
     xd, Wd, y = dev(nhwc(x)), dev(split16(rowperm_pad(Wm, NB * 32))), dev(nhwc(skip))
-    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 3, 1, ptr(xd), c, ptr(Wd), 0, None, ptr(y), ptr(y), 2 * c, NB, T, H, W)
+    rc = ctx._lib.ira_op_naf_pw(ctx.handle, 3, 1, ptr(xd), c, ptr(Wd), 0, None, ptr(y), ptr(y), 2 * c, NB, T, H, W, None)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(y.cpu(), nhwc(ref), 2e-5)
 
@@ -224,6 +253,15 @@ def test_forward_matches_oracle_256_batch():
     # batch independence: image 1 alone gives bit-identical output
     y1 = be.forward(x[1:2].numpy())
     assert np.array_equal(y1[0], y[1])
+    # the per-op kernel path (fused tail off) agrees with the fused one to rounding
+    be.set_fused_ffn(False)
+    try:
+        yu = be.forward(x.numpy())
+    finally:
+        be.set_fused_ffn(True)
+    pu = O.psnr_f(yu, ref)
+    print(f"  per-op path: PSNR vs oracle {pu:.2f} dB, fused vs per-op {O.psnr_f(y, yu):.2f} dB")
+    assert pu >= 58.0
 
 
 def test_forward_device_nhwc_and_errors():
