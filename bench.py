@@ -55,25 +55,23 @@ def family_elements(family, C, Hf):
 
 
 def nafnet_elements_per_px(cfg):
-    """Fusion contract for NAFNet in the style of SURVEY 8d: per NAFBlock and level-pixel 7c elements
-    (LN+conv1+dw+gate: read c, write c; conv3+residual: read 2c, write c; LN+conv4+gate+conv5+residual: read c, write c),
-    plus the U-Net glue (intro 3+w, ending w+3+3, downs c+2c per source/target pixel, ups 2c+c+c)."""
-    w = cfg.width
-    L = len(cfg.enc_blk_nums)
-    tot = 3 + w + w + 6.0
+    """SURVEY 8d NAFNet contract: per NAFBlock and level-pixel N1 LN+conv1 (read c, write 2c), N2 dw3x3+SimpleGate+pool
+    partials (read 2c, write c), N3 SCA x conv3 x beta + residual (read 2c, write c), N4 LN+conv4+gate+conv5 x gamma +
+    residual (read c, write c) = 11c; summed over the levels (4x fewer pixels each) + 313 glue elements (intro, ending +
+    skip, downs, ups + skip add; scaled by width/32).  Width 32, enc [2,2,4,8] / middle 12 / dec [2,2,2,2]: 3 657 per px."""
+    w, L = cfg.width, len(cfg.enc_blk_nums)
+    tot = 313.0 * w / 32.0
     for l in range(L + 1):
-        c = w << l
         n = cfg.middle_blk_num if l == L else cfg.enc_blk_nums[l] + cfg.dec_blk_nums[L - 1 - l]
-        tot += 7.0 * c * n / 4 ** l
-        if l < L:
-            tot += c / 4 ** l + 2 * c / 4 ** (l + 1)            # down: read c at level l, write 2c at level l+1
-            tot += 2 * c / 4 ** (l + 1) + 2 * c / 4 ** l        # up: read 2c at level l+1, read skip c + write c at level l
+        tot += 11.0 * (w << l) * n / 4 ** l
     return tot
 
 
 def nafnet_family_elements(family, c):
-    return {'naf_ln_conv1': 3 * c, 'naf_dw_gate': 3 * c, 'naf_sca_fold': 0, 'naf_conv3_res': 3 * c, 'naf_ln_conv4': 3 * c,
-            'naf_gate_conv5_res': 4 * c}.get(family, 0)
+    """Algorithmic elements per level-pixel of one kernel family under that contract (N4 split over its two per-op kernels;
+    the fused tail covers N3 + N4)."""
+    return {'naf_ln_conv1': 3 * c, 'naf_dw_gate': 3 * c, 'naf_sca': 0, 'naf_conv3_res': 3 * c, 'naf_ln_conv4': c,
+            'naf_gate_conv5_res': c, 'naf_tail_fused': 5 * c}.get(family, 0)
 
 
 def nafnet_macs_per_px(cfg):

@@ -7,7 +7,8 @@ FETCH_SIZE reports half of the bytes of a wide coalesced read, so reads = 2 * FE
 WRITE_SIZE * 1024 is exact for 16-byte-per-lane stores.  Dispatches are matched across passes by
 (kernel name, grid size, ordinal), which is valid because the command is deterministic.
 
-usage: prof_summary.py <dir with prof_trace/ prof_fetch/ prof_write/> [out.md] [traffic.json]
+usage: prof_summary.py <dir with <prefix>_trace/ <prefix>_fetch/ <prefix>_write/> [out.md] [traffic.json] [--prefix prof]
+(traffic.json is merged into, not overwritten)
 """
 import csv
 import json
@@ -48,9 +49,14 @@ def load_pmc(path, counter):
 
 def main():
     d = sys.argv[1]
-    tr = load_trace(f'{d}/prof_trace/trace_kernel_trace.csv')
-    fe = load_pmc(f'{d}/prof_fetch/fetch_counter_collection.csv', 'FETCH_SIZE')
-    wr = load_pmc(f'{d}/prof_write/write_counter_collection.csv', 'WRITE_SIZE')
+    pfx = 'prof'
+    if '--prefix' in sys.argv:
+        i = sys.argv.index('--prefix')
+        pfx = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    tr = load_trace(f'{d}/{pfx}_trace/trace_kernel_trace.csv')
+    fe = load_pmc(f'{d}/{pfx}_fetch/fetch_counter_collection.csv', 'FETCH_SIZE')
+    wr = load_pmc(f'{d}/{pfx}_write/write_counter_collection.csv', 'WRITE_SIZE')
     total = sum(sum(v) for v in tr.values())
     out = []
     out.append('| kernel | grid (threads) | calls | avg us | % time | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | HBM GB/s |')
@@ -76,11 +82,22 @@ def main():
                 if patches == T_ * ((side + 7) // 8) * ((side + 31) // 32):
                     traffic[f'{m_.group(1)}_fused|C{m_.group(2)}|{side}x{side}|T{T_}'] = int(2.0 * 1024 * sum(fe[key]) / len(fe[key]) + 1024.0 * sum(wr[key]) / len(wr[key]))
                     break
+    # NAFNet bench (16 tiles of 512x512): the two level-1 kernels bench.py can name as dominant
+    for key in list(tr.keys()):
+        for pat, fam, grids in ((r'k_naf_dw_sg', 'naf_dw_gate', {4194304: ('C32', 512), 2097152: ('C64', 256)}),
+                                (r'k_naf_tail<32>|k_naf_tailILi32', 'naf_tail_fused', {1048576: ('C32', 512)}),
+                                (r'k_naf_tail<64>|k_naf_tailILi64', 'naf_tail_fused', {262144: ('C64', 256)})):
+            if _re.search(pat, key[0]) and key[1] in grids and key in fe and key in wr:
+                cc, side = grids[key[1]]
+                traffic[f'{fam}|{cc}|{side}x{side}|T16'] = int(2.0 * 1024 * sum(fe[key]) / len(fe[key]) + 1024.0 * sum(wr[key]) / len(wr[key]))
     text = f'total kernel time {total / 1e6:.2f} ms over {sum(len(v) for v in tr.values())} dispatches\n\n' + '\n'.join(out) + '\n'
     if len(sys.argv) > 2:
         open(sys.argv[2], 'w').write(text)
     if len(sys.argv) > 3:
-        json.dump(traffic, open(sys.argv[3], 'w'), indent=1)
+        import os
+        old = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+        old.update(traffic)
+        json.dump(old, open(sys.argv[3], 'w'), indent=1)
     print(text)
 
 
