@@ -48,7 +48,7 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const 
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);
 
 hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out,
-                        int T, int H, int W, int ic, int C);
+                        int T, int H, int W, int ic, int C, int relu = 0);
 
 hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx);
 

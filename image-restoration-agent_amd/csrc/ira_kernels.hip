@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ att
 // OverlapPatchEmbed is k_embed below; this one serves Downsample / Upsample / output
 // (restormer_arch.py:171-189,243,281).   in fp32 NHWC [T][H][Wd][K]; W fp16 [9][NBtot*32][K]; out fp32.
 // MODE 0 plain [T][H][Wd][N]; 1 PixelUnshuffle(2) -> [T][H/2][Wd/2][4N]; 2 PixelShuffle(2) ->
-// [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281).
+// [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281); 4 plain + ReLU (DnCNN body).
 // W: fragment-major [2][9][NBtot][K/16][64][8] (hi, lo planes).  The fp32 input is split into fp16 hi + lo in registers as well
 // (three MFMAs per step: Wh.xh + Wl.xh + Wh.xl), so the conv sees ~fp32 operands at no extra traffic.
 template <int NBW, int MODE>
@@ -865,6 +865,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
                 const float val = acc[nb][8 * u + j];
                 if constexpr (MODE == 0) {
                     out[((long)t * P + p) * N + n] = val;
+                } else if constexpr (MODE == 4) {
+                    out[((long)t * P + p) * N + n] = fmaxf(val, 0.f);
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -977,6 +979,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
                 const float val = acc[nb][8 * u + j];
                 if constexpr (MODE == 0) {
                     out[((long)t * P + p) * N + n] = val;
+                } else if constexpr (MODE == 4) {
+                    out[((long)t * P + p) * N + n] = fmaxf(val, 0.f);
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -995,7 +999,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
 // fp32 like the reference; 0.1% of the FLOPs).  One thread = one pixel x 8 output channels.
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, const float* __restrict__ w,
                                                const float* __restrict__ bias, float* __restrict__ out, int T,
-                                               int H, int W, int ic, int C) {
+                                               int H, int W, int ic, int C, int relu) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [9*ic][C]: (tap, ci) major, channel minor
     for (int i = threadIdx.x; i < C * ic * 9; i += blockDim.x) {
         const int o = i / (ic * 9), rem = i % (ic * 9), ci = rem / 9, tap = rem % 9;
@@ -1029,6 +1033,10 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, con
                 for (int e = 0; e < 4; ++e) { acc[e] = fmaf(v, w0[e], acc[e]); acc[4 + e] = fmaf(v, w1[e], acc[4 + e]); }
             }
         }
+    }
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
     }
     float* dst = out + px * C + g * 8;
     *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -1337,15 +1345,16 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const 
         case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
         case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
         case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        case 4: return conv3x3_dispatch<4>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
         default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out, int T, int H,
-                        int W, int ic, int C) {
+                        int W, int ic, int C, int relu) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)T * H * W * (C / 8);
-    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), (size_t)C * ic * 9 * sizeof(float), st, in, w, bias, out, T, H, W, ic, C);
+    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), (size_t)C * ic * 9 * sizeof(float), st, in, w, bias, out, T, H, W, ic, C, relu);
     return hipGetLastError();
 }
 

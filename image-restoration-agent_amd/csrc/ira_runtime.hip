@@ -43,9 +43,14 @@ struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into th
 
 struct ira_model {
     int device = -1;
-    int arch = 0;                    // 0 Restormer, 1 NAFNet
+    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN
     ira_restormer_config cfg{};
     ira_nafnet_config ncfg{};
+    ira_dncnn_config dcfg{};
+    const float *dn_first_w = nullptr, *dn_first_b = nullptr, *dn_last_b = nullptr;
+    const void* dn_last_w = nullptr;
+    std::vector<const void*> dn_mid_w;
+    std::vector<const float*> dn_mid_b;
     // NAFNet weights / workspace
     std::vector<std::vector<NBlk>> nenc, ndec;
     std::vector<NBlk> nmid;
@@ -545,7 +550,53 @@ int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, floa
     return IRA_OK;
 }
 
+// =============================================================================================
+// DnCNN (BASELINE config 1; no reference code: a build-defined plumbing model, see ira_amd/dncnn.py):
+// conv3x3(in->nc)+ReLU, (nb-2) x [conv3x3(nc->nc) + BN (folded by the packer) + ReLU], conv3x3(nc->in); out = x - net(x).
+bool dn_bind_weights(ira_model* m) {
+    const ira_dncnn_config& c = m->dcfg;
+    m->err.clear();
+    m->dn_first_w = (const float*)wptr(m, "first_w", true, (size_t)c.nc * c.in_nc * 9 * 4);
+    m->dn_first_b = (const float*)wptr(m, "first_b", true, (size_t)c.nc * 4);
+    m->dn_last_w = wptr(m, "last_w", true, (size_t)2 * 9 * up32(c.in_nc) * c.nc * 2);
+    m->dn_last_b = (const float*)wptr(m, "last_b", true, (size_t)up32(c.in_nc) * 4);
+    if (!m->dn_first_w || !m->dn_first_b || !m->dn_last_w || !m->dn_last_b) return false;
+    m->dn_mid_w.assign(c.nb - 2, nullptr); m->dn_mid_b.assign(c.nb - 2, nullptr);
+    for (int i = 0; i < c.nb - 2; ++i) {
+        m->dn_mid_w[i] = wptr(m, "mid." + std::to_string(i) + "_w", true, (size_t)2 * 9 * up32(c.nc) * c.nc * 2);
+        m->dn_mid_b[i] = (const float*)wptr(m, "mid." + std::to_string(i) + "_b", true, (size_t)up32(c.nc) * 4);
+        if (!m->dn_mid_w[i] || !m->dn_mid_b[i]) return false;
+    }
+    return true;
+}
+
+int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    const ira_dncnn_config& c = m->dcfg;
+    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
+    if (!(m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W)) {
+        if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
+        const size_t one = al256((size_t)T * H * W * c.nc * 4);
+        hipError_t e = hipMalloc((void**)&m->ws, 2 * one);
+        if (e != hipSuccess) { m->ws = nullptr; m->ws_T = 0; return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu): %s", 2 * one, hipGetErrorString(e)); }
+        m->ws_bytes = 2 * one; m->ws_T = T; m->ws_H = H; m->ws_W = W;
+        m->nx.assign(2, nullptr);
+        m->nx[0] = (float*)m->ws; m->nx[1] = (float*)(m->ws + one);
+    }
+    hipStream_t st = m->st;
+    const int nbc = up32(c.nc) / 32;
+    float *a = m->nx[0], *b = m->nx[1];
+    RUN(m, "dncnn_first3x3_relu", ira::launch_embed(st, in, m->dn_first_w, m->dn_first_b, a, T, H, W, c.in_nc, c.nc, 1));
+    for (int i = 0; i < c.nb - 2; ++i) {
+        RUN(m, "dncnn_conv3x3_bn_relu", ira::launch_conv3x3(st, a, m->dn_mid_w[i], m->dn_mid_b[i], nullptr, b, 4, T, H, W, c.nc, c.nc, nbc));
+        std::swap(a, b);
+    }
+    // weights and bias of the last conv are negated by the packer: out = x + (-(conv)) = x - noise
+    RUN(m, "dncnn_last3x3_residual", ira::launch_conv3x3(st, a, m->dn_last_w, m->dn_last_b, in, out, 3, T, H, W, c.nc, c.in_nc, up32(c.in_nc) / 32));
+    return IRA_OK;
+}
+
 int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    if (m->arch == 2) return dn_forward_enqueue(m, in, T, H, W, out);
     return m->arch == 1 ? naf_forward_enqueue(m, in, T, H, W, out) : restormer_forward_enqueue(m, in, T, H, W, out);
 }
 
@@ -728,6 +779,26 @@ int ira_nafnet_create(int device, const ira_nafnet_config* cfg, const void* blob
     return IRA_OK;
 }
 
+int ira_dncnn_create(int device, const ira_dncnn_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_dncnn_create: NULL argument");
+    *out = nullptr;
+    if (cfg->in_nc != 1 && cfg->in_nc != 3) return gfail(IRA_ERR_ARG, "in_nc must be 1 or 3, got %d", cfg->in_nc);
+    if (cfg->nc < 16 || cfg->nc % 16 != 0) return gfail(IRA_ERR_ARG, "nc must be a positive multiple of 16, got %d", cfg->nc);
+    if (cfg->nb < 2) return gfail(IRA_ERR_ARG, "nb must be >= 2, got %d", cfg->nb);
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 2; m->dcfg = *cfg;
+    m->cfg.inp_channels = m->cfg.out_channels = cfg->in_nc;
+    if (!dn_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
+    *out = m;
+    return IRA_OK;
+}
+
 int ira_model_destroy(ira_model_t* m) {
     if (!m) return IRA_OK;
     hipSetDevice(m->device);
@@ -769,7 +840,7 @@ int ira_forward_device(ira_model_t* m, const float* in, int B, int H, int W, flo
 int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, float* out) {
     ENTER(m);
     if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_forward: NULL buffer");
-    const int ic = m->arch == 1 ? m->ncfg.img_channel : m->cfg.inp_channels;
+    const int ic = m->cfg.inp_channels;      // set by every create function
     if (C != ic) return m->fail(IRA_ERR_ARG, "ira_forward: C=%d but the model has inp_channels=%d", C, ic);
     if (B <= 0 || H <= 0 || W <= 0 || (m->arch == 0 && ((H & 7) || (W & 7))))
         return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);

@@ -36,6 +36,10 @@ class IraNafnetConfig(C.Structure):
     ]
 
 
+class IraDncnnConfig(C.Structure):
+    _fields_ = [('in_nc', C.c_int32), ('nc', C.c_int32), ('nb', C.c_int32)]
+
+
 _vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 _pi = C.POINTER(C.c_int)
 
@@ -44,6 +48,7 @@ SIGNATURES = {
     'ira_device_count': (_i, [_pi]),
     'ira_model_create': (_i, [_i, C.POINTER(IraConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_nafnet_create': (_i, [_i, C.POINTER(IraNafnetConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_dncnn_create': (_i, [_i, C.POINTER(IraDncnnConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_model_destroy': (_i, [_vp]),
     'ira_last_error': (C.c_char_p, [_vp]),
     'ira_sync': (_i, [_vp]),

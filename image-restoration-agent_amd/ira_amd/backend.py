@@ -167,3 +167,12 @@ class NAFNetBackend(_Backend):
         from .nafnet import pack_nafnet_blob, nafnet_cfg_struct
         self.cfg = cfg
         self._create(device, 'ira_nafnet_create', nafnet_cfg_struct(cfg), pack_nafnet_blob(state_dict, cfg), 'ira_nafnet_create')
+
+
+class DnCNNBackend(_Backend):
+    """The build-defined DnCNN (BASELINE config 1; no reference code exists: see ira_amd/dncnn.py)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .dncnn import pack_dncnn_blob, dncnn_cfg_struct
+        self.cfg = cfg
+        self._create(device, 'ira_dncnn_create', dncnn_cfg_struct(cfg), pack_dncnn_blob(state_dict, cfg), 'ira_dncnn_create')

@@ -69,6 +69,15 @@ typedef struct ira_nafnet_config {
     int32_t dec_blk_nums[IRA_NAFNET_MAX_LEVELS];      /* {2,2,2,2} */
 } ira_nafnet_config;
 
+/* DnCNN (BASELINE config 1).  The reference contains no DnCNN code: this is the build-defined
+ * plumbing model of ira_amd/dncnn.py: conv3x3(in_nc->nc)+ReLU, (nb-2) x [conv3x3(nc->nc)+BatchNorm+ReLU],
+ * conv3x3(nc->in_nc), output = input - network(input).  BatchNorm (eval) is folded into the convs by the packer. */
+typedef struct ira_dncnn_config {
+    int32_t in_nc;     /* 1 (grayscale) or 3 */
+    int32_t nc;        /* 64 */
+    int32_t nb;        /* 17 conv layers */
+} ira_dncnn_config;
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
@@ -86,6 +95,9 @@ int ira_model_create(int device, const ira_restormer_config* cfg,
  * replaces: NAFNet(**opt); load_state_dict; eval  (NAFNet_arch.py:251-299). */
 int ira_nafnet_create(int device, const ira_nafnet_config* cfg,
                       const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* DnCNN: blob from ira_amd/dncnn.py::pack_dncnn_blob; any H, W. */
+int ira_dncnn_create(int device, const ira_dncnn_config* cfg,
+                     const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
 int ira_model_destroy(ira_model_t* model);
 
 /* Text of the last error on this handle (or, with model == NULL, of the last failed call that had
@@ -192,7 +204,8 @@ int ira_op_attn_mix(ira_model_t* m, const float* part_dev, const float* wo_dev, 
 
 /* Dense 3x3 conv, zero pad, fp32 NHWC in (T,H,W,K) -> fp32 out.  W fp16 [9][NB*32][K].
  * mode 0: plain (T,H,W,N); 1: + PixelUnshuffle(2) -> (T,H/2,W/2,4N)  (restormer_arch.py:171-179);
- * 2: + PixelShuffle(2) -> (T,2H,2W,N/4) (:181-189); 3: final conv + input skip (:281), skip fp32 (T,H,W,N). */
+ * 2: + PixelShuffle(2) -> (T,2H,2W,N/4) (:181-189); 3: final conv + input skip (:281), skip fp32 (T,H,W,N);
+ * 4: plain + ReLU (DnCNN body). */
 int ira_op_conv3x3(ira_model_t* m, const float* in_dev, const void* W_f16_dev, const float* bias_dev,
                    const float* skip_dev, float* out_dev, int mode, int T, int H, int W, int K, int N, int NB);
 
