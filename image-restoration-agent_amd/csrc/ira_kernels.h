@@ -60,6 +60,12 @@ hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int
 hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c, int Hp, int Wp, int th, int tw,
                         int stride_h, int stride_w, int n_rows, int n_cols, uint8_t* out);
 
+// pad-crop tiler (xrestormer_model.py:53-136): desc[n][6] = {tile y0, x0, core y0, x0, core h, w} in padded-frame coordinates
+hipError_t launch_extract_list(hipStream_t st, const uint8_t* frame, int h, int w, int c, int th, int tw, const int* desc,
+                               int n_tiles, float* tiles);
+hipError_t launch_scatter_cores(hipStream_t st, const float* tiles, int th, int tw, int c, const int* desc, int n_tiles,
+                                int max_core, int h, int w, uint8_t* out);
+
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
 hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
 

@@ -1081,6 +1081,49 @@ __global__ __launch_bounds__(256) void k_extract_tiles(const uint8_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pad-crop tiler of the X-Restormer / HAT style harness (X-Restormer/xrestormer/models/xrestormer_model.py:53-136):
+// reflect-pad the frame on the bottom/right to a multiple of padding_size (pre_process :53-63), cut NON-overlapping
+// tile_size cores, run each with a tile_pad halo clipped at the padded frame (:83-95), keep the core (:119-133), crop
+// (:134-136).  Tiles are grouped by shape on the host; desc[n][6] = {y0, x0 of the haloed tile, core y0, x0, core h, w},
+// all in padded-frame coordinates.
+__global__ __launch_bounds__(256) void k_extract_list(const uint8_t* __restrict__ frame, int h, int w, int c, int th, int tw,
+                                                      const int* __restrict__ desc, int n_tiles, float* __restrict__ tiles) {
+    const long total = (long)n_tiles * th * tw * c;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        long rest = idx / c;
+        const int xx = (int)(rest % tw); rest /= tw;
+        const int yy = (int)(rest % th);
+        const int tl = (int)(rest / th);
+        int Y = desc[tl * 6 + 0] + yy, X = desc[tl * 6 + 1] + xx;
+        if (Y >= h) Y = 2 * (h - 1) - Y;     // F.pad(..., 'reflect') :63
+        if (X >= w) X = 2 * (w - 1) - X;
+        tiles[idx] = __fdiv_rn((float)frame[((long)Y * w + X) * c + ch], 255.0f);
+    }
+}
+
+// core of every tile -> uint8 frame: clamp(0,1), rint(x*255); pixels in the pre_process padding are dropped (:134-136)
+__global__ __launch_bounds__(256) void k_scatter_cores(const float* __restrict__ tiles, int th, int tw, int c,
+                                                       const int* __restrict__ desc, int n_tiles, int max_core, int h, int w,
+                                                       uint8_t* __restrict__ out) {
+    const long total = (long)n_tiles * max_core * c;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        long rest = idx / c;
+        const int q = (int)(rest % max_core);
+        const int tl = (int)(rest / max_core);
+        const int* d = desc + tl * 6;
+        const int cw = d[5], chh = d[4];
+        if (q >= cw * chh) continue;
+        const int dy = q / cw, dx = q % cw;
+        const int Y = d[2] + dy, X = d[3] + dx;
+        if (Y >= h || X >= w) continue;
+        const float v = tiles[(((long)tl * th + (d[2] - d[0] + dy)) * tw + (d[3] - d[1] + dx)) * c + ch];
+        out[((long)Y * w + X) * c + ch] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
+    }
+}
+
 // E += tile, W += 1 in row-major tile order; E/W; clamp; crop; rint(x*255) (demo.py:145-161).
 __global__ __launch_bounds__(256) void k_blend(const float* __restrict__ tiles, int h, int w, int c, int Hp, int Wp,
                                                int th, int tw, int stride_h, int stride_w, int n_rows, int n_cols,
@@ -1370,6 +1413,20 @@ hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int
     const long total = (long)n_tiles * th * tw * c;
     hipLaunchKernelGGL(k_extract_tiles, dim3(grid1d(total, 256, 65536)), dim3(256), 0, st, frame, h, w, c, Hp, Wp, th, tw,
                        stride_h, stride_w, n_rows, n_cols, first_tile, n_tiles, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_list(hipStream_t st, const uint8_t* frame, int h, int w, int c, int th, int tw, const int* desc,
+                               int n_tiles, float* tiles) {
+    hipLaunchKernelGGL(k_extract_list, dim3(grid1d((long)n_tiles * th * tw * c, 256, 65536)), dim3(256), 0, st, frame, h, w, c, th, tw,
+                       desc, n_tiles, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_cores(hipStream_t st, const float* tiles, int th, int tw, int c, const int* desc, int n_tiles,
+                                int max_core, int h, int w, uint8_t* out) {
+    hipLaunchKernelGGL(k_scatter_cores, dim3(grid1d((long)n_tiles * max_core * c, 256, 65536)), dim3(256), 0, st, tiles, th, tw, c,
+                       desc, n_tiles, max_core, h, w, out);
     return hipGetLastError();
 }
 

@@ -933,6 +933,83 @@ int ira_restore_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int t
     return rc;
 }
 
+int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int tile_size, int tile_pad, int padding_size,
+                           uint8_t* out) {
+    ENTER(m);
+    if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_restore_padcrop_u8: NULL buffer");
+    if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
+    if (h <= 0 || w <= 0 || padding_size <= 0 || tile_pad < 0) return m->fail(IRA_ERR_ARG, "bad size / padding arguments");
+    // pre_process (xrestormer_model.py:53-63)
+    const int mph = (h % padding_size) ? padding_size - h % padding_size : 0;
+    const int mpw = (w % padding_size) ? padding_size - w % padding_size : 0;
+    if (mph >= h || mpw >= w) return m->fail(IRA_ERR_ARG, "reflect padding needs pad < image size (F.pad 'reflect')");
+    const int Hp = h + mph, Wp = w + mpw;
+    // tile_process (:65-133); tile_size <= 0: the untiled branch of test() (:138-150)
+    struct D { int v[6]; };
+    std::map<std::pair<int, int>, std::vector<D>> classes;
+    const int ts = tile_size > 0 ? tile_size : std::max(Hp, Wp);
+    const int tiles_x = (Wp + ts - 1) / ts, tiles_y = (Hp + ts - 1) / ts;
+    for (int y = 0; y < tiles_y; ++y)
+        for (int x = 0; x < tiles_x; ++x) {
+            const int sx = x * ts, ex = std::min(sx + ts, Wp), sy = y * ts, ey = std::min(sy + ts, Hp);
+            const int sxp = std::max(sx - tile_pad, 0), exp_ = std::min(ex + tile_pad, Wp);
+            const int syp = std::max(sy - tile_pad, 0), eyp = std::min(ey + tile_pad, Hp);
+            D d{{syp, sxp, sy, sx, ey - sy, ex - sx}};
+            classes[{eyp - syp, exp_ - sxp}].push_back(d);
+        }
+    if (m->arch == 0)
+        for (auto& kv : classes)
+            if ((kv.first.first & 7) || (kv.first.second & 7))
+                return m->fail(IRA_ERR_ARG, "tile %dx%d is not a multiple of 8: choose tile_size, tile_pad, padding_size as multiples of 8",
+                               kv.first.first, kv.first.second);
+    const size_t fbytes = (size_t)h * w * c;
+    uint8_t *fin = nullptr, *fout = nullptr; float *tin = nullptr, *tout = nullptr; int* ddev = nullptr;
+    auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tin) hipFree(tin); if (tout) hipFree(tout); if (ddev) hipFree(ddev); };
+    size_t max_batch_elems = 0, max_desc = 0;
+    std::map<std::pair<int, int>, int> batch_of;
+    for (auto& kv : classes) {
+        const long px = (long)kv.first.first * kv.first.second;
+        int b = m->max_batch > 0 ? m->max_batch : (int)std::max(1L, std::min(256L, (64L * 512 * 512) / std::max(px, 1L)));
+        b = std::min<int>(b, (int)kv.second.size());
+        batch_of[kv.first] = b;
+        max_batch_elems = std::max(max_batch_elems, (size_t)b * px * c);
+        max_desc = std::max(max_desc, kv.second.size());
+    }
+    hipError_t e;
+    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, fbytes)) != hipSuccess ||
+        (e = hipMalloc((void**)&tin, max_batch_elems * 4)) != hipSuccess || (e = hipMalloc((void**)&tout, max_batch_elems * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&ddev, max_desc * sizeof(D))) != hipSuccess) {
+        cleanup();
+        return m->fail(IRA_ERR_OOM, "ira_restore_padcrop_u8: hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = IRA_OK;
+    do {
+        if ((e = hipMemcpyAsync(fin, in, fbytes, hipMemcpyHostToDevice, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
+        for (auto& kv : classes) {
+            const int th = kv.first.first, tw = kv.first.second, n = (int)kv.second.size(), batch = batch_of[kv.first];
+            // the descriptor buffer is reused by the next class: drain the stream before overwriting it
+            if ((e = hipStreamSynchronize(m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
+            if ((e = hipMemcpy(ddev, kv.second.data(), (size_t)n * sizeof(D), hipMemcpyHostToDevice)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "descriptor upload: %s", hipGetErrorString(e)); break; }
+            int max_core = 0;
+            for (const D& d : kv.second) max_core = std::max(max_core, d.v[4] * d.v[5]);
+            for (int t0 = 0; t0 < n && rc == IRA_OK; t0 += batch) {
+                const int nbt = std::min(batch, n - t0);
+                rc = run(m, "padcrop_extract", [&]() { return ira::launch_extract_list(m->st, fin, h, w, c, th, tw, ddev + (size_t)t0 * 6, nbt, tin); });
+                if (rc != IRA_OK) break;
+                if ((rc = forward_enqueue(m, tin, nbt, th, tw, tout)) != IRA_OK) break;
+                rc = run(m, "padcrop_scatter", [&]() { return ira::launch_scatter_cores(m->st, tout, th, tw, c, ddev + (size_t)t0 * 6, nbt, max_core, h, w, fout); });
+            }
+            if (rc != IRA_OK) break;
+        }
+        if (rc != IRA_OK) break;
+        if ((e = hipMemcpyAsync(out, fout, fbytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
+        if ((e = hipStreamSynchronize(m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc != IRA_OK) hipStreamSynchronize(m->st);
+    cleanup();
+    return rc;
+}
+
 int ira_set_max_batch(ira_model_t* m, int max_tiles) {
     ENTER(m);
     if (max_tiles < 0) return m->fail(IRA_ERR_ARG, "max_tiles must be >= 0");

@@ -100,6 +100,19 @@ class _Backend:
         self._ck(rc, 'ira_restore_u8')
         return out
 
+    def restore_padcrop(self, img_u8: np.ndarray, tile_size=None, tile_pad: int = 32, padding_size: int = 64) -> np.ndarray:
+        """The reference's other tiler (xrestormer_model.py:53-136: reflect-pad to ``padding_size``, non-overlapping
+        ``tile_size`` cores with a ``tile_pad`` halo, crop): uint8 (h,w,c) -> uint8 (h,w,c)."""
+        img = np.ascontiguousarray(img_u8)
+        if img.dtype != np.uint8 or img.ndim != 3:
+            raise ValueError("expected a uint8 (h,w,c) array")
+        h, w, c = img.shape
+        out = np.empty_like(img)
+        rc = self._lib.ira_restore_padcrop_u8(self._h, img.ctypes.data, h, w, c, int(tile_size) if tile_size else 0,
+                                              int(tile_pad), int(padding_size), out.ctypes.data)
+        self._ck(rc, 'ira_restore_padcrop_u8')
+        return out
+
     def restore_tiles_device(self, frame_ptr: int, h: int, w: int, c: int, tile, overlap: int,
                              first_tile: int, n_tiles: int, out_ptr: int):
         rc = self._lib.ira_restore_tiles_device(self._h, frame_ptr, h, w, c, int(tile) if tile else 0, int(overlap),

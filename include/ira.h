@@ -135,6 +135,14 @@ int ira_tile_plan(int h, int w, int tile, int overlap,
 int ira_restore_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h, int w, int c,
                    int tile, int overlap, uint8_t* out_hwc_host);
 
+/* The other tiler of the reference, used by its X-Restormer / HAT style tools (X-Restormer/xrestormer/models/
+ * xrestormer_model.py:53-136): reflect-pad bottom/right to a multiple of padding_size (pre_process :53-63), run
+ * NON-overlapping tile_size cores, each with a tile_pad halo clipped at the padded frame (:83-95), keep the cores
+ * (:119-133), crop (:134-136); then clamp(0,1) -> rint(x*255) (basicsr tensor2img).  tile_size <= 0: untiled (:138-150).
+ * Works with every model handle (scale 1).  uint8 HWC host buffers. */
+int ira_restore_padcrop_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h, int w, int c,
+                           int tile_size, int tile_pad, int padding_size, uint8_t* out_hwc_host);
+
 /* Sharded form for one-process-per-GPU tile parallelism.  All pointers are device
  * memory.  frame: uint8 (h,w,c), unpadded.  Runs tiles [first_tile, first_tile+n_tiles) of the
  * row-major tile list through the network and writes them, float32 NHWC (n_tiles,tile_h,tile_w,c),

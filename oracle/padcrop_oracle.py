@@ -1,0 +1,47 @@
+"""CPU ORACLE for the pad-crop tiler -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Restates X-Restormer/xrestormer/models/xrestormer_model.py: pre_process :53-63, tile_process :65-133, post_process
+:134-136, for scale 1, around any ``forward_fn`` (NCHW float tensor -> same).  The uint8 conversion around it
+(SingleImageDataset / tensor2img) lives in pip basicsr, which is not in /root/reference: at that boundary parity is UNPINNED
+(SURVEY 8c); it is restated as /255 in, clamp(0,1) -> round-half-even(x*255) out, like the Restormer harness."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def padcrop_restore(lq, forward_fn, tile_size=None, tile_pad=32, padding_size=64):
+    """lq: (1,C,h,w) float tensor -> (1,C,h,w)."""
+    _, _, h, w = lq.shape
+    mod_pad_h = padding_size - h % padding_size if h % padding_size != 0 else 0          # :58-61
+    mod_pad_w = padding_size - w % padding_size if w % padding_size != 0 else 0
+    lq = F.pad(lq, (0, mod_pad_w, 0, mod_pad_h), 'reflect')                              # :63
+    if not tile_size:
+        out = forward_fn(lq)                                                             # test() :138-150
+    else:
+        b, c, height, width = lq.shape
+        out = lq.new_zeros(lq.shape)                                                     # :77
+        tiles_x, tiles_y = math.ceil(width / tile_size), math.ceil(height / tile_size)   # :78-79
+        for y in range(tiles_y):
+            for x in range(tiles_x):
+                sx, sy = x * tile_size, y * tile_size                                    # :85-86
+                ex, ey = min(sx + tile_size, width), min(sy + tile_size, height)         # :88-91
+                sxp, exp_ = max(sx - tile_pad, 0), min(ex + tile_pad, width)             # :94-95
+                syp, eyp = max(sy - tile_pad, 0), min(ey + tile_pad, height)             # :96-97
+                tile = forward_fn(lq[:, :, syp:eyp, sxp:exp_])                           # :103-114
+                oy, ox = sy - syp, sx - sxp                                              # :125-128
+                out[:, :, sy:ey, sx:ex] = tile[:, :, oy:oy + (ey - sy), ox:ox + (ex - sx)]   # :131-133
+    _, _, H, W = out.shape
+    return out[:, :, 0:H - mod_pad_h, 0:W - mod_pad_w]                                   # :134-136
+
+
+def padcrop_restore_image(img_u8, forward_fn, tile_size=None, tile_pad=32, padding_size=64):
+    """uint8 (h,w,c) -> uint8 (h,w,c)."""
+    x = torch.from_numpy(np.ascontiguousarray(img_u8)).float().div(255.).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        y = padcrop_restore(x, forward_fn, tile_size, tile_pad, padding_size)
+    y = torch.clamp(y, 0, 1)[0].permute(1, 2, 0).numpy()
+    return np.rint(y.astype(np.float32) * np.float32(255.0)).astype(np.uint8)
