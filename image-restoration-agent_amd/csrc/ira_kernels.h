@@ -10,7 +10,7 @@ namespace ira {
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K,
                           const void* W, const float* bias, void* y, int y_stride, int n_store,
-                          int NB, int T, int P, float eps = 1e-5f);
+                          int NB, int T, int P, float eps = 1e-5f, int ln_n = 0, int act = 0);   // ln_n: true channel count when K is zero-padded; act 1 = GELU
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                           const void* W, long w_tile_stride, const float* bias, const float* resid,
@@ -45,7 +45,7 @@ hipError_t launch_ffn_fused12(hipStream_t st, const float* x, float* x_out, int 
                               int T, int H, int W, int Hp);
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
-                          const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB);
+                          const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope = 0.f);
 
 hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out,
                         int T, int H, int W, int ic, int C, int relu = 0);
@@ -55,7 +55,7 @@ hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b
 // tiler
 hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int w, int c, int Hp, int Wp,
                                 int th, int tw, int stride_h, int stride_w, int n_rows, int n_cols,
-                                int first_tile, int n_tiles, float* tiles);
+                                int first_tile, int n_tiles, float* tiles, int flip = 0);   // flip 1: flip-concat padding (SwinIR harness)
 
 hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c, int Hp, int Wp, int th, int tw,
                         int stride_h, int stride_w, int n_rows, int n_cols, uint8_t* out);
@@ -84,5 +84,18 @@ bool naf_tail_supported(int c);
 hipError_t launch_naf_tail(hipStream_t st, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,
                            const void* W4, const float* b4, const void* W5, const float* b5, int T, int P);
 hipError_t launch_naf_pad_crop(hipStream_t st, const float* in, float* out, int T, int Hi, int Wi, int Ho, int Wo, int C);
+
+// ---- SwinIR (ira_swinir.hip)
+// (shifted-)window attention: qkv fp16 [T][H][W][3*heads*32] ([q|k|v][head][32]), bias fp32 [heads][64][64], out fp16 [T][H][W][heads*32]
+hipError_t launch_swin_attn(hipStream_t st, const void* qkv, const float* bias, void* out, int T, int H, int W, int heads,
+                            int ws, int shift);
+hipError_t launch_ln_affine(hipStream_t st, const float* x, const float* g, const float* b, float* y, long npx, int C, int Cp,
+                            float eps);
+hipError_t launch_swin_pre(hipStream_t st, const float* in, float* out, int T, int H, int W, int Hp, int Wp, int c,
+                           const float* mean3, float range);
+hipError_t launch_swin_post(hipStream_t st, const float* in, float* out, int T, int Hi, int Wi, int Ho, int Wo, int c,
+                            const float* mean3, float range);
+hipError_t launch_nearest2x(hipStream_t st, const float* in, float* out, int T, int H, int W, int C);
+hipError_t launch_lrelu(hipStream_t st, float* x, long n, float slope);
 
 }  // namespace ira

@@ -87,7 +87,7 @@ IRA_DEV float gelu_erf(float x) {
 template <int KS, int LN, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, f16* __restrict__ y,
-                                                 int y_stride, int n_store, int NB, int T, int P, float eps) {
+                                                 int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     constexpr int K = KS * 16;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int chunks = (P + 32 * PG - 1) / (32 * PG);
@@ -121,14 +121,17 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
 #pragma unroll
                     for (int j = 0; j < 8; ++j) sum += xv[s][j];
                 sum += __shfl_xor(sum, 32);
-                const float mu = sum * (1.0f / K);
+                // ln_n < K: channels [ln_n, K) are zero padding (SwinIR's 180 -> 192): statistics over ln_n channels
+                const float inv_n = 1.0f / (float)ln_n;
+                const float mu = sum * inv_n;
                 float sq = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const float d = xv[s][j] - mu; sq += d * d; }
                 sq += __shfl_xor(sq, 32);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / K) + eps);
+                sq -= (float)(K - ln_n) * mu * mu;
+                const float rstd = 1.0f / sqrtf(sq * inv_n + eps);
                 const float sub = (LN == 2) ? mu : 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
@@ -182,6 +185,10 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
                 const int n0 = 32 * nb + 16 * u + 8 * h;
                 if (valid[g] && n0 + 8 <= n_store) {
                     half8 o;
+                    if (act == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[g][8 * u + j] = gelu_erf(acc[g][8 * u + j]);
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (f16)acc[g][8 * u + j];
                     *(half8*)(y + px[g] * y_stride + n0) = o;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
 template <int KS, int LN, bool IN_F32>
 __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xin, const f16* __restrict__ W,
                                                      const float* __restrict__ bias, f16* __restrict__ y,
-                                                     int y_stride, int n_store, int NB, int T, int P, float eps) {
+                                                     int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     constexpr int K = KS * 16;
     constexpr int F = 2 * KS;                 // fragments (1 KB each) per 32-row weight block: hi plane then lo plane
     constexpr int SH = F / 4;                 // fragments each wave stages per block
@@ -331,7 +338,8 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
             }
             sum += __shfl_xor(sum, 32);
         }
-        const float mu = sum * (1.0f / K);
+        const float inv_n = 1.0f / (float)ln_n;
+        const float mu = sum * inv_n;
         if constexpr (LN != 0) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -340,8 +348,9 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
                 for (int j = 0; j < 4; ++j) { const float d0 = lo[j] - mu, d1 = hi[j] - mu; sq += d0 * d0 + d1 * d1; }
             }
             sq += __shfl_xor(sq, 32);
+            sq -= (float)(K - ln_n) * mu * mu;
         }
-        const float rstd = (LN != 0) ? 1.0f / sqrtf(sq * (1.0f / K) + eps) : 1.0f;
+        const float rstd = (LN != 0) ? 1.0f / sqrtf(sq * inv_n + eps) : 1.0f;
         const float sub = (LN == 2) ? mu : 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -395,6 +404,10 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
             const int n0 = 32 * nb + 16 * u + 8 * h;
             if (valid && n0 + 8 <= n_store) {
                 half8 o;
+                if (act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[8 * u + j] = gelu_erf(acc[8 * u + j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (f16)acc[8 * u + j];
                 *(half8*)(y + px * y_stride + n0) = o;
@@ -791,14 +804,14 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ att
 // OverlapPatchEmbed is k_embed below; this one serves Downsample / Upsample / output
 // (restormer_arch.py:171-189,243,281).   in fp32 NHWC [T][H][Wd][K]; W fp16 [9][NBtot*32][K]; out fp32.
 // MODE 0 plain [T][H][Wd][N]; 1 PixelUnshuffle(2) -> [T][H/2][Wd/2][4N]; 2 PixelShuffle(2) ->
-// [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281); 4 plain + ReLU (DnCNN body).
+// [T][2H][2Wd][N/4]; 3 plain + skip (the "+ inp_img" of :281); 4 plain + LeakyReLU(slope) (slope 0 = ReLU: DnCNN body; 0.2 / 0.01: SwinIR).
 // W: fragment-major [2][9][NBtot][K/16][64][8] (hi, lo planes).  The fp32 input is split into fp16 hi + lo in registers as well
 // (three MFMAs per step: Wh.xh + Wl.xh + Wh.xl), so the conv sees ~fp32 operands at no extra traffic.
 template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, const float* __restrict__ skip,
                                                  float* __restrict__ out, int T, int H, int Wd, int K, int N,
-                                                 int NBtot) {
+                                                 int NBtot, float slope) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int P = H * Wd;
     const int chunks = (P + 31) >> 5;
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
                 if constexpr (MODE == 0) {
                     out[((long)t * P + p) * N + n] = val;
                 } else if constexpr (MODE == 4) {
-                    out[((long)t * P + p) * N + n] = fmaxf(val, 0.f);
+                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -887,7 +900,7 @@ template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ in, const f16* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ skip,
                                                      float* __restrict__ out, int T, int H, int Wd, int K, int N,
-                                                     int NBtot) {
+                                                     int NBtot, float slope) {
     constexpr int F = 2 * NBW;
     constexpr int SH = (F + 3) / 4;
     __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
@@ -980,7 +993,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
                 if constexpr (MODE == 0) {
                     out[((long)t * P + p) * N + n] = val;
                 } else if constexpr (MODE == 4) {
-                    out[((long)t * P + p) * N + n] = fmaxf(val, 0.f);
+                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -1064,7 +1077,7 @@ IRA_DEV int tile_origin(int i, int n, int stride, int full, int tile) { return (
 __global__ __launch_bounds__(256) void k_extract_tiles(const uint8_t* __restrict__ frame, int h, int w, int c,
                                                        int Hp, int Wp, int th, int tw, int stride_h, int stride_w,
                                                        int n_rows, int n_cols, int first_tile, int n_tiles,
-                                                       float* __restrict__ tiles) {
+                                                       float* __restrict__ tiles, int flip) {
     const long total = (long)n_tiles * th * tw * c;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % c);
@@ -1075,8 +1088,10 @@ __global__ __launch_bounds__(256) void k_extract_tiles(const uint8_t* __restrict
         const int ri = tl / n_cols, ci = tl % n_cols;
         int Y = tile_origin(ri, n_rows, stride_h, Hp, th) + yy;
         int X = tile_origin(ci, n_cols, stride_w, Wp, tw) + xx;
-        if (Y >= h) Y = 2 * (h - 1) - Y;     // F.pad(..., 'reflect') on the bottom / right edge
-        if (X >= w) X = 2 * (w - 1) - X;
+        // bottom / right padding: F.pad(..., 'reflect') (demo.py:127), or with flip = 1 the flip-concatenation
+        // torch.cat([img, flip(img)]) of SwinIR/inference.py:79-80 (row h + i is row h - 1 - i)
+        if (Y >= h) Y = 2 * (h - 1) - Y + flip;
+        if (X >= w) X = 2 * (w - 1) - X + flip;
         tiles[idx] = __fdiv_rn((float)frame[((long)Y * w + X) * c + ch], 255.0f);
     }
 }
@@ -1190,10 +1205,10 @@ static int env_int(const char* name, int dflt) {
 
 template <int KS, int PG>
 static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
-                                 f16* y, int ys, int ns, int NB, int T, int P, float eps) {
+                                 f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
     const long waves = (long)T * ((P + 32 * PG - 1) / (32 * PG));
     const dim3 grid(grid1d(waves, 4)), block(256);
-#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_, PG>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P, eps)
+#define IRA_KRES(LN_, F32_) hipLaunchKernelGGL((k_pw_kres<KS, LN_, F32_, PG>), grid, block, 0, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act)
     if (in_f32) {
         if (ln == 0) IRA_KRES(0, true); else if (ln == 1) IRA_KRES(1, true); else IRA_KRES(2, true);
     } else {
@@ -1206,7 +1221,7 @@ static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int
 
 template <int KS>
 static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
-                                     f16* y, int ys, int ns, int NB, int T, int P, float eps) {
+                                     f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
     const long waves = (long)T * ((P + 31) / 32);
     const long wgs = (waves + 3) / 4;
     int splits = 1;
@@ -1217,7 +1232,7 @@ static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32,
     do {                                                                                                                \
         static bool done_ = false;                                                                                      \
         if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
-        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps);      \
+        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);      \
     } while (0)
     if (in_f32) {
         if (ln == 0) IRA_KL(0, true); else if (ln == 1) IRA_KL(1, true); else IRA_KL(2, true);
@@ -1231,26 +1246,26 @@ static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32,
 
 template <int KS>
 static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W,
-                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P, float eps) {
+                                   const float* bias, f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
     static const int lds_env = env_int("IRA_PW_LDS", 1);
-    if constexpr (KS >= 16) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps);
+    if constexpr (KS >= 16) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);
     else {
-    if constexpr (KS >= 12) { if (lds_env) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
+    if constexpr (KS >= 12) { if (lds_env) return pw_kres_lds_launch<KS>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act); }
     static const int pg_env = env_int("IRA_KRES_PG", 0);
     int pg = pg_env > 0 ? pg_env : (KS <= 4 ? 4 : (KS <= 12 ? 2 : 1));
     while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;        // tiny tiles: do not pad a wave with empty groups
-    if constexpr (KS <= 6) { if (pg >= 4) return pw_kres_launch<KS, 4>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
-    if constexpr (KS <= 12) { if (pg >= 2) return pw_kres_launch<KS, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps); }
-    return pw_kres_launch<KS, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps);
+    if constexpr (KS <= 6) { if (pg >= 4) return pw_kres_launch<KS, 4>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act); }
+    if constexpr (KS <= 12) { if (pg >= 2) return pw_kres_launch<KS, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act); }
+    return pw_kres_launch<KS, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);
     }
 }
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
-                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps) {
+                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
     const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
     switch (K / 16) {
-#define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P, eps);
+#define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P, eps, ln_n, act);
         IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(8) IRA_CASE(12) IRA_CASE(16) IRA_CASE(24) IRA_CASE(32)
 #undef IRA_CASE
         default: return hipErrorInvalidValue;
@@ -1301,7 +1316,7 @@ hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1
     const f16* Wh = (const f16*)W;
     switch (NB) {
 #define IRA_CASE(NB_) case NB_: return pw_nres_dispatch<NB_>(st, x0, K0, x1, K1, in_f32, Wh, w_tile_stride, bias, resid, y, N, T, P);
-        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(12)
+        IRA_CASE(1) IRA_CASE(2) IRA_CASE(3) IRA_CASE(4) IRA_CASE(6) IRA_CASE(8) IRA_CASE(12)
 #undef IRA_CASE
         default: return hipErrorInvalidValue;
     }
@@ -1354,41 +1369,41 @@ hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, c
 
 template <int MODE>
 static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W, const float* bias,
-                                   const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB) {
+                                   const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB, float slope) {
     const long waves = (long)T * (((long)H * Wd + 31) / 32);
     const int NBW = NB >= 6 ? 6 : (NB >= 3 ? 3 : (NB == 2 ? 2 : 1));
     const dim3 grid(grid1d(waves, 4), (NB + NBW - 1) / NBW), block(256);
     static const int lds_env = env_int("IRA_CONV_LDS", 1);
     if (lds_env && NB >= 2) {      // every multi-block conv: weights through LDS
         switch (NBW) {
-            case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
-            case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
-            default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+            case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
         }
         return hipGetLastError();
     }
     switch (NBW) {
-        case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
-        case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
-        case 3: hipLaunchKernelGGL((k_conv3x3<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
-        default: hipLaunchKernelGGL((k_conv3x3<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB); break;
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+        default: hipLaunchKernelGGL((k_conv3x3<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias, const float* skip,
-                          float* out, int mode, int T, int H, int Wd, int K, int N, int NB) {
+                          float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope) {
     if (K % 16 != 0 || NB * 32 < N) return hipErrorInvalidValue;
     if (mode == 1 && ((H | Wd) & 1)) return hipErrorInvalidValue;
     if (mode == 2 && (N & 3)) return hipErrorInvalidValue;
     if (mode == 3 && skip == nullptr) return hipErrorInvalidValue;
     const f16* Wh = (const f16*)W;
     switch (mode) {
-        case 0: return conv3x3_dispatch<0>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
-        case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
-        case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
-        case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
-        case 4: return conv3x3_dispatch<4>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB);
+        case 0: return conv3x3_dispatch<0>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
+        case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
+        case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
+        case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
+        case 4: return conv3x3_dispatch<4>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1409,10 +1424,10 @@ hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b
 
 hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int w, int c, int Hp, int Wp, int th,
                                 int tw, int stride_h, int stride_w, int n_rows, int n_cols, int first_tile,
-                                int n_tiles, float* tiles) {
+                                int n_tiles, float* tiles, int flip) {
     const long total = (long)n_tiles * th * tw * c;
     hipLaunchKernelGGL(k_extract_tiles, dim3(grid1d(total, 256, 65536)), dim3(256), 0, st, frame, h, w, c, Hp, Wp, th, tw,
-                       stride_h, stride_w, n_rows, n_cols, first_tile, n_tiles, tiles);
+                       stride_h, stride_w, n_rows, n_cols, first_tile, n_tiles, tiles, flip);
     return hipGetLastError();
 }
 

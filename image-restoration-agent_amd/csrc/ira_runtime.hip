@@ -30,6 +30,17 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
 
 struct Prof { long launches = 0; double ms = 0; };
 
+struct SBlk {  // one SwinTransformerBlock (network_swinir.py:164-279)
+    const void* qkv_w = nullptr; const float* qkv_b = nullptr; const float* bias_tab = nullptr;
+    const void* proj_w = nullptr; const float* proj_b = nullptr;
+    const void* fc1_w = nullptr; const float* fc1_b = nullptr;
+    const void* fc2_w = nullptr; const float* fc2_b = nullptr;
+};
+struct SConv {  // '1conv' (w0 only) or '3conv' (3x3, 1x1, 3x3) residual connection conv (:462-469, :727-735)
+    const void *w0 = nullptr, *w2 = nullptr, *w4 = nullptr;
+    const float *b0 = nullptr, *b2 = nullptr, *b4 = nullptr;
+};
+
 struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into the weight blob
     const void* c1_w = nullptr;  const float* c1_b = nullptr;     // conv1 with norm1 folded in
     const float* dw_w = nullptr; const float* dw_b = nullptr;     // conv2 (depthwise 3x3)
@@ -43,10 +54,20 @@ struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into th
 
 struct ira_model {
     int device = -1;
-    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN
+    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR
     ira_restormer_config cfg{};
     ira_nafnet_config ncfg{};
     ira_dncnn_config dcfg{};
+    ira_swinir_config scfg{};
+    std::vector<std::vector<SBlk>> sw_blocks;
+    std::vector<SConv> sw_lconv;
+    SConv sw_cab;
+    const float *sw_first_w = nullptr, *sw_first_b = nullptr, *sw_pe_g = nullptr, *sw_pe_b = nullptr, *sw_norm_g = nullptr, *sw_norm_b = nullptr;
+    const void *sw_cbu_w = nullptr, *sw_up_w[2] = {nullptr, nullptr}, *sw_hr_w = nullptr, *sw_last_w = nullptr;
+    const float *sw_cbu_b = nullptr, *sw_up_b[2] = {nullptr, nullptr}, *sw_hr_b = nullptr, *sw_last_b = nullptr;
+    float *sw_xp = nullptr, *sw_xf = nullptr, *sw_xa = nullptr, *sw_xb = nullptr, *sw_c1 = nullptr, *sw_c2 = nullptr, *sw_ua = nullptr, *sw_ub = nullptr,
+          *sw_y = nullptr;
+    void *sw_qkv = nullptr, *sw_att = nullptr, *sw_hid = nullptr;
     const float *dn_first_w = nullptr, *dn_first_b = nullptr, *dn_last_b = nullptr;
     const void* dn_last_w = nullptr;
     std::vector<const void*> dn_mid_w;
@@ -595,12 +616,210 @@ int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float
     return IRA_OK;
 }
 
+// =============================================================================================
+// SwinIR (network_swinir.py:618-840): weights, workspace, forward schedule
+struct SwGeo { int C, Cp, hid, hidp, qp, heads_max; };
+SwGeo sw_geo(const ira_swinir_config& c) {
+    SwGeo g;
+    g.C = c.embed_dim; g.Cp = up32(c.embed_dim); g.hid = c.mlp_hidden; g.hidp = up32(c.mlp_hidden); g.qp = up32(c.embed_dim / 4);
+    g.heads_max = 0;
+    for (int i = 0; i < c.n_layers; ++i) g.heads_max = std::max(g.heads_max, c.num_heads[i]);
+    return g;
+}
+
+bool sw_load_conv(ira_model* m, const std::string& p, bool three, const SwGeo& g, SConv& c) {
+    if (!three) {
+        c.w0 = wptr(m, p + "_w", true, (size_t)2 * 9 * g.Cp * g.Cp * 2);
+        c.b0 = (const float*)wptr(m, p + "_b", true, (size_t)g.Cp * 4);
+        return c.w0 && c.b0;
+    }
+    c.w0 = wptr(m, p + ".0_w", true, (size_t)2 * 9 * g.qp * g.Cp * 2);
+    c.b0 = (const float*)wptr(m, p + ".0_b", true, (size_t)g.qp * 4);
+    c.w2 = wptr(m, p + ".2_w", true, (size_t)2 * g.qp * g.qp * 2);
+    c.b2 = (const float*)wptr(m, p + ".2_b", true, (size_t)g.qp * 4);
+    c.w4 = wptr(m, p + ".4_w", true, (size_t)2 * 9 * g.Cp * g.qp * 2);
+    c.b4 = (const float*)wptr(m, p + ".4_b", true, (size_t)g.Cp * 4);
+    return c.w0 && c.b0 && c.w2 && c.b2 && c.w4 && c.b4;
+}
+
+bool sw_bind_weights(ira_model* m) {
+    const ira_swinir_config& c = m->scfg;
+    const SwGeo g = sw_geo(c);
+    const bool three = c.resi_3conv != 0;
+    m->err.clear();
+    m->sw_first_w = (const float*)wptr(m, "first_w", true, (size_t)g.Cp * c.in_chans * 9 * 4);
+    m->sw_first_b = (const float*)wptr(m, "first_b", true, (size_t)g.Cp * 4);
+    m->sw_pe_g = (const float*)wptr(m, "pe_norm_g", true, (size_t)g.Cp * 4);
+    m->sw_pe_b = (const float*)wptr(m, "pe_norm_b", true, (size_t)g.Cp * 4);
+    m->sw_norm_g = (const float*)wptr(m, "norm_g", true, (size_t)g.Cp * 4);
+    m->sw_norm_b = (const float*)wptr(m, "norm_b", true, (size_t)g.Cp * 4);
+    if (!m->sw_first_w || !m->sw_first_b || !m->sw_pe_g || !m->sw_pe_b || !m->sw_norm_g || !m->sw_norm_b) return false;
+    m->sw_blocks.assign(c.n_layers, {});
+    m->sw_lconv.assign(c.n_layers, SConv());
+    for (int i = 0; i < c.n_layers; ++i) {
+        const int heads = c.num_heads[i], Kh = heads * 32;
+        m->sw_blocks[i].resize(c.depths[i]);
+        for (int k = 0; k < c.depths[i]; ++k) {
+            const std::string p = "l" + std::to_string(i) + ".b" + std::to_string(k);
+            SBlk& b = m->sw_blocks[i][k];
+            b.qkv_w = wptr(m, p + ".qkv_w", true, (size_t)2 * 3 * Kh * g.Cp * 2);
+            b.qkv_b = (const float*)wptr(m, p + ".qkv_b", true, (size_t)3 * Kh * 4);
+            b.bias_tab = (const float*)wptr(m, p + ".bias_tab", true, (size_t)heads * 64 * 64 * 4);
+            b.proj_w = wptr(m, p + ".proj_w", true, (size_t)2 * g.Cp * Kh * 2);
+            b.proj_b = (const float*)wptr(m, p + ".proj_b", true, (size_t)g.Cp * 4);
+            b.fc1_w = wptr(m, p + ".fc1_w", true, (size_t)2 * g.hidp * g.Cp * 2);
+            b.fc1_b = (const float*)wptr(m, p + ".fc1_b", true, (size_t)g.hidp * 4);
+            b.fc2_w = wptr(m, p + ".fc2_w", true, (size_t)2 * g.Cp * g.hidp * 2);
+            b.fc2_b = (const float*)wptr(m, p + ".fc2_b", true, (size_t)g.Cp * 4);
+            if (!b.qkv_w || !b.qkv_b || !b.bias_tab || !b.proj_w || !b.proj_b || !b.fc1_w || !b.fc1_b || !b.fc2_w || !b.fc2_b) return false;
+        }
+        if (!sw_load_conv(m, "l" + std::to_string(i) + ".conv", three, g, m->sw_lconv[i])) return false;
+    }
+    if (!sw_load_conv(m, "cab", three, g, m->sw_cab)) return false;
+    const int nf = 64, oc32 = up32(c.in_chans);
+    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
+    auto bb = [&](const char* n, int N) { return (const float*)wptr(m, n, true, (size_t)up32(N) * 4); };
+    if (c.upsampler == 0) {
+        m->sw_last_w = c3("last_w", g.Cp, c.in_chans); m->sw_last_b = bb("last_b", c.in_chans);
+        return m->sw_last_w && m->sw_last_b;
+    }
+    m->sw_cbu_w = c3("cbu_w", g.Cp, nf); m->sw_cbu_b = bb("cbu_b", nf);
+    const int n_up = c.upscale == 4 ? 2 : (c.upscale == 2 ? 1 : 0);
+    for (int j = 0; j < n_up; ++j) {
+        const std::string n = "up" + std::to_string(j);
+        const int N = c.upsampler == 1 ? 4 * nf : nf;
+        m->sw_up_w[j] = c3((n + "_w").c_str(), nf, N); m->sw_up_b[j] = bb((n + "_b").c_str(), N);
+        if (!m->sw_up_w[j] || !m->sw_up_b[j]) return false;
+    }
+    if (c.upsampler == 2) {
+        m->sw_hr_w = c3("hr_w", nf, nf); m->sw_hr_b = bb("hr_b", nf);
+        if (!m->sw_hr_w || !m->sw_hr_b) return false;
+    }
+    m->sw_last_w = c3("last_w", nf, c.in_chans); m->sw_last_b = bb("last_b", c.in_chans);
+    (void)oc32;
+    return m->sw_cbu_w && m->sw_cbu_b && m->sw_last_w && m->sw_last_b;
+}
+
+int sw_ensure_workspace(ira_model* m, int T, int Hp, int Wp) {
+    if (m->ws && T <= m->ws_T && Hp == m->ws_H && Wp == m->ws_W) return IRA_OK;
+    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
+    const ira_swinir_config& c = m->scfg;
+    const SwGeo g = sw_geo(c);
+    const size_t tp = (size_t)T * Hp * Wp, s2 = (size_t)c.upscale * c.upscale;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    const size_t o_xp = take(tp * c.in_chans * 4), o_xf = take(tp * g.Cp * 4), o_xa = take(tp * g.Cp * 4), o_xb = take(tp * g.Cp * 4);
+    const size_t o_qkv = take(tp * 3 * g.heads_max * 32 * 2), o_att = take(tp * g.heads_max * 32 * 2), o_hid = take(tp * g.hidp * 2);
+    const size_t o_c1 = take(c.resi_3conv ? tp * g.qp * 4 : 256), o_c2 = take(c.resi_3conv ? tp * g.qp * 4 : 256);
+    const size_t ub = c.upsampler ? tp * s2 * 64 * 4 : 256;
+    const size_t o_ua = take(ub), o_ub = take(ub), o_y = take(tp * s2 * c.in_chans * 4);
+    hipError_t e = hipMalloc((void**)&m->ws, off);
+    if (e != hipSuccess) {
+        m->ws = nullptr; m->ws_T = 0;
+        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, Hp, Wp, hipGetErrorString(e));
+    }
+    m->ws_bytes = off; m->ws_T = T; m->ws_H = Hp; m->ws_W = Wp;
+    char* b = m->ws;
+    m->sw_xp = (float*)(b + o_xp); m->sw_xf = (float*)(b + o_xf); m->sw_xa = (float*)(b + o_xa); m->sw_xb = (float*)(b + o_xb);
+    m->sw_qkv = b + o_qkv; m->sw_att = b + o_att; m->sw_hid = b + o_hid;
+    m->sw_c1 = (float*)(b + o_c1); m->sw_c2 = (float*)(b + o_c2); m->sw_ua = (float*)(b + o_ua); m->sw_ub = (float*)(b + o_ub);
+    m->sw_y = (float*)(b + o_y);
+    return IRA_OK;
+}
+
+// y (may alias skip) = resi_conv(x) + skip   ('1conv' / '3conv')
+int sw_resi_conv(ira_model* m, const SConv& cv, const float* x, const float* skip, float* y, int T, int H, int W, const char* fam) {
+    const ira_swinir_config& c = m->scfg;
+    const SwGeo g = sw_geo(c);
+    hipStream_t st = m->st;
+    if (!c.resi_3conv) {
+        RUN(m, fam, ira::launch_conv3x3(st, x, cv.w0, cv.b0, skip, y, 3, T, H, W, g.Cp, g.Cp, g.Cp / 32));
+        return IRA_OK;
+    }
+    RUN(m, fam, ira::launch_conv3x3(st, x, cv.w0, cv.b0, nullptr, m->sw_c1, 4, T, H, W, g.Cp, g.qp, g.qp / 32, 0.2f));
+    RUN(m, fam, ira::launch_naf_pw(st, 3, 0, m->sw_c1, g.qp, cv.w2, 0, cv.b2, nullptr, m->sw_c2, g.qp, g.qp / 32, T, H, W));
+    RUN(m, fam, ira::launch_lrelu(st, m->sw_c2, (long)T * H * W * g.qp, 0.2f));
+    RUN(m, fam, ira::launch_conv3x3(st, m->sw_c2, cv.w4, cv.b4, skip, y, 3, T, H, W, g.qp, g.Cp, g.Cp / 32));
+    return IRA_OK;
+}
+
+int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    const ira_swinir_config& c = m->scfg;
+    const SwGeo g = sw_geo(c);
+    const int ws = c.window_size, s = c.upscale, ic = c.in_chans;
+    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
+    const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;                       // check_image_size :783-788
+    if (Hp - H >= H || Wp - W >= W) return m->fail(IRA_ERR_ARG, "reflect padding needs pad < image size (F.pad 'reflect')");
+    int rc = sw_ensure_workspace(m, T, Hp, Wp);
+    if (rc != IRA_OK) return rc;
+    hipStream_t st = m->st;
+    const int P = Hp * Wp;
+    static const float rgb_mean[3] = {0.4488f, 0.4371f, 0.4040f};                             // :659-662
+    static const float zero_mean[3] = {0.f, 0.f, 0.f};
+    const float* mean = ic == 3 ? rgb_mean : zero_mean;
+    RUN(m, "swin_pre", ira::launch_swin_pre(st, in, m->sw_xp, T, H, W, Hp, Wp, ic, mean, c.img_range));                      // :807-810
+    RUN(m, "swin_conv_first", ira::launch_embed(st, m->sw_xp, m->sw_first_w, m->sw_first_b, m->sw_xf, T, Hp, Wp, ic, g.Cp));   // :814
+    RUN(m, "swin_layernorm", ira::launch_ln_affine(st, m->sw_xf, m->sw_pe_g, m->sw_pe_b, m->sw_xa, (long)T * P, g.C, g.Cp, 1e-5f));   // :792
+    char k_[5][64];
+    for (int i = 0; i < c.n_layers; ++i) {
+        const int heads = c.num_heads[i], Kh = heads * 32;
+        if (m->profile) {
+            const char* fam[5] = {"swin_ln_qkv", "swin_window_attn", "swin_proj_res", "swin_ln_fc1_gelu", "swin_fc2_res"};
+            for (int q = 0; q < 5; ++q) snprintf(k_[q], sizeof k_[q], "%s|C%d|%dx%d|T%d", fam[q], g.C, Hp, Wp, T);
+        } else {
+            for (int q = 0; q < 5; ++q) k_[q][0] = 0;
+        }
+        HIP_TRY(m, hipMemcpyAsync(m->sw_xb, m->sw_xa, (size_t)T * P * g.Cp * 4, hipMemcpyDeviceToDevice, st));     // RSTB keeps its input (:482)
+        float* x = m->sw_xb;
+        for (int k = 0; k < c.depths[i]; ++k) {
+            const SBlk& b = m->sw_blocks[i][k];
+            const int shift = (k % 2 == 0) ? 0 : ws / 2;                                                             // :385-386
+            RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0));
+            RUN(m, k_[1], ira::launch_swin_attn(st, m->sw_qkv, b.bias_tab, m->sw_att, T, Hp, Wp, heads, ws, shift));
+            RUN(m, k_[2], ira::launch_pw_nres(st, m->sw_att, Kh, nullptr, 0, false, b.proj_w, 0, b.proj_b, x, x, g.Cp, g.Cp / 32, T, P));
+            RUN(m, k_[3], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.fc1_w, b.fc1_b, m->sw_hid, g.hidp, g.hidp, g.hidp / 32, T, P, 1e-5f, g.C, 1));
+            RUN(m, k_[4], ira::launch_pw_nres(st, m->sw_hid, g.hidp, nullptr, 0, false, b.fc2_w, 0, b.fc2_b, x, x, g.Cp, g.Cp / 32, T, P));
+        }
+        if ((rc = sw_resi_conv(m, m->sw_lconv[i], x, m->sw_xa, m->sw_xa, T, Hp, Wp, "swin_rstb_conv"))) return rc;
+    }
+    RUN(m, "swin_layernorm", ira::launch_ln_affine(st, m->sw_xa, m->sw_norm_g, m->sw_norm_b, m->sw_xb, (long)T * P, g.C, g.Cp, 1e-5f));  // :800
+    if ((rc = sw_resi_conv(m, m->sw_cab, m->sw_xb, m->sw_xf, m->sw_xa, T, Hp, Wp, "swin_conv_after_body"))) return rc;                    // + x_first
+    const float* body = m->sw_xa;
+    const int nb64 = 2, nbo = up32(ic) / 32;
+    int Ho = Hp, Wo = Wp;
+    if (c.upsampler == 0) {                                                                                          // :835-837
+        RUN(m, "swin_conv_last", ira::launch_conv3x3(st, body, m->sw_last_w, m->sw_last_b, m->sw_xp, m->sw_y, 3, T, Hp, Wp, g.Cp, ic, nbo));
+    } else {
+        float *ua = m->sw_ua, *ub = m->sw_ub;
+        RUN(m, "swin_conv_before_upsample", ira::launch_conv3x3(st, body, m->sw_cbu_w, m->sw_cbu_b, nullptr, ua, 4, T, Hp, Wp, g.Cp, 64, nb64, 0.01f));
+        const int n_up = s == 4 ? 2 : (s == 2 ? 1 : 0);
+        for (int j = 0; j < n_up; ++j) {
+            if (c.upsampler == 1) {                                                                                  // Upsample :580-592
+                RUN(m, "swin_upsample_conv_shuffle", ira::launch_conv3x3(st, ua, m->sw_up_w[j], m->sw_up_b[j], nullptr, ub, 2, T, Ho, Wo, 64, 256, 8));
+                std::swap(ua, ub);
+            } else {                                                                                                 // :830-833
+                RUN(m, "swin_nearest2x", ira::launch_nearest2x(st, ua, ub, T, Ho, Wo, 64));
+                RUN(m, "swin_conv_up", ira::launch_conv3x3(st, ub, m->sw_up_w[j], m->sw_up_b[j], nullptr, ua, 4, T, 2 * Ho, 2 * Wo, 64, 64, nb64, 0.2f));
+            }
+            Ho *= 2; Wo *= 2;
+        }
+        if (c.upsampler == 2) {
+            RUN(m, "swin_conv_hr", ira::launch_conv3x3(st, ua, m->sw_hr_w, m->sw_hr_b, nullptr, ub, 4, T, Ho, Wo, 64, 64, nb64, 0.2f));
+            std::swap(ua, ub);
+        }
+        RUN(m, "swin_conv_last", ira::launch_conv3x3(st, ua, m->sw_last_w, m->sw_last_b, nullptr, m->sw_y, 0, T, Ho, Wo, 64, ic, nbo));
+    }
+    RUN(m, "swin_post", ira::launch_swin_post(st, m->sw_y, out, T, Ho, Wo, H * s, W * s, ic, mean, c.img_range));   // :838-840
+    return IRA_OK;
+}
+
 int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    if (m->arch == 3) return sw_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 2) return dn_forward_enqueue(m, in, T, H, W, out);
     return m->arch == 1 ? naf_forward_enqueue(m, in, T, H, W, out) : restormer_forward_enqueue(m, in, T, H, W, out);
 }
 
-struct Plan { int Hp, Wp, th, tw, sh, sw, n_rows, n_cols; };
+struct Plan { int Hp, Wp, th, tw, sh, sw, n_rows, n_cols; int flip = 0, scale = 1; };
 
 int make_plan(int h, int w, int tile, int overlap, Plan& p, std::string& err) {
     if (h <= 0 || w <= 0) { err = "image size must be positive"; return IRA_ERR_ARG; }
@@ -624,6 +843,33 @@ int make_plan(int h, int w, int tile, int overlap, Plan& p, std::string& err) {
     return IRA_OK;
 }
 
+// The harness of the model's architecture: Restormer's demo.py rule above, or SwinIR's (SwinIR/inference.py:76-80,294-310):
+// ALWAYS pad to (h // ws + 1) * ws by flip-concatenation, tile a multiple of the window, outputs scaled by `upscale`.
+int plan_for(const ira_model* m, int h, int w, int tile, int overlap, Plan& p, std::string& err) {
+    if (m->arch != 3) return make_plan(h, w, tile, overlap, p, err);
+    if (h <= 0 || w <= 0) { err = "image size must be positive"; return IRA_ERR_ARG; }
+    const int ws = m->scfg.window_size;
+    p.flip = 1; p.scale = m->scfg.upscale;
+    p.Hp = (h / ws + 1) * ws; p.Wp = (w / ws + 1) * ws;
+    if (p.Hp - h > h || p.Wp - w > w) { err = "flip padding needs pad <= image size (torch.cat([img, flip(img)]))"; return IRA_ERR_ARG; }
+    if (tile <= 0) { p.th = p.Hp; p.tw = p.Wp; p.sh = p.Hp; p.sw = p.Wp; p.n_rows = 1; p.n_cols = 1; return IRA_OK; }
+    const int t = std::min(tile, std::min(p.Hp, p.Wp));                       // inference.py:301
+    if (t % ws != 0) { err = "tile size should be a multiple of window_size"; return IRA_ERR_ARG; }   // :302
+    const int stride = t - overlap;
+    if (stride <= 0) { err = "tile_overlap must be smaller than the tile (range() step must be positive)"; return IRA_ERR_ARG; }
+    p.th = p.tw = t; p.sh = p.sw = stride;
+    p.n_rows = (p.Hp - t + stride - 1) / stride + 1;                          // :306-308
+    p.n_cols = (p.Wp - t + stride - 1) / stride + 1;
+    return IRA_OK;
+}
+
+int blend_enqueue(ira_model* m, const float* tiles, int h, int w, int c, const Plan& p, uint8_t* out) {
+    const int s = p.scale;
+    RUN(m, "tile_blend", ira::launch_blend(m->st, tiles, h * s, w * s, c, p.Hp * s, p.Wp * s, p.th * s, p.tw * s, p.sh * s, p.sw * s,
+                                           p.n_rows, p.n_cols, out));
+    return IRA_OK;
+}
+
 int default_batch(const ira_model* m, const Plan& p) {
     if (m->max_batch > 0) return m->max_batch;
     // up to 64 tiles of 512x512 per launch-batch (about 1 GB of workspace per such tile; a 4K frame is 40):
@@ -637,14 +883,15 @@ int restore_tiles_enqueue(ira_model* m, const uint8_t* frame_dev, int h, int w, 
                           int n, float* tiles_out) {
     const int batch = default_batch(m, p);
     const size_t tile_elems = (size_t)p.th * p.tw * c;
+    const size_t tile_elems_out = tile_elems * p.scale * p.scale;
     int rc = ensure_scratch(m, al256((size_t)batch * tile_elems * 4));
     if (rc != IRA_OK) return rc;
     float* tin = (float*)m->hs;
     for (int t0 = 0; t0 < n; t0 += batch) {
         const int nb = std::min(batch, n - t0);
         RUN(m, "tile_extract", ira::launch_extract_tiles(m->st, frame_dev, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw,
-                                                         p.n_rows, p.n_cols, first + t0, nb, tin));
-        rc = forward_enqueue(m, tin, nb, p.th, p.tw, tiles_out + (size_t)t0 * tile_elems);
+                                                         p.n_rows, p.n_cols, first + t0, nb, tin, p.flip));
+        rc = forward_enqueue(m, tin, nb, p.th, p.tw, tiles_out + (size_t)t0 * tile_elems_out);
         if (rc != IRA_OK) return rc;
     }
     return IRA_OK;
@@ -799,6 +1046,36 @@ int ira_dncnn_create(int device, const ira_dncnn_config* cfg, const void* blob, 
     return IRA_OK;
 }
 
+int ira_swinir_create(int device, const ira_swinir_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_swinir_create: NULL argument");
+    *out = nullptr;
+    if (cfg->in_chans != 1 && cfg->in_chans != 3) return gfail(IRA_ERR_ARG, "in_chans must be 1 or 3, got %d", cfg->in_chans);
+    if (cfg->window_size != 7 && cfg->window_size != 8) return gfail(IRA_ERR_ARG, "window_size must be 7 or 8 (the reference's configs), got %d", cfg->window_size);
+    if (cfg->embed_dim < 16 || cfg->embed_dim % 4 != 0 || cfg->embed_dim > 512) return gfail(IRA_ERR_ARG, "embed_dim %d unsupported (multiple of 4, 16..512)", cfg->embed_dim);
+    if (cfg->n_layers < 1 || cfg->n_layers > IRA_SWINIR_MAX_LAYERS) return gfail(IRA_ERR_ARG, "n_layers out of range");
+    for (int i = 0; i < cfg->n_layers; ++i) {
+        if (cfg->depths[i] < 1 || cfg->num_heads[i] < 1 || cfg->embed_dim % cfg->num_heads[i] != 0 || cfg->embed_dim / cfg->num_heads[i] > 32)
+            return gfail(IRA_ERR_ARG, "layer %d: depth %d heads %d (head_dim must divide embed_dim and be <= 32)", i, cfg->depths[i], cfg->num_heads[i]);
+    }
+    if (cfg->mlp_hidden < 1) return gfail(IRA_ERR_ARG, "mlp_hidden must be positive");
+    if (cfg->upsampler < 0 || cfg->upsampler > 2) return gfail(IRA_ERR_ARG, "upsampler must be 0 (''), 1 (pixelshuffle) or 2 (nearest+conv)");
+    if (cfg->upsampler == 0 ? cfg->upscale != 1 : (cfg->upscale != 1 && cfg->upscale != 2 && cfg->upscale != 4))
+        return gfail(IRA_ERR_ARG, "upscale %d unsupported for this upsampler (1 without; 1, 2 or 4 with)", cfg->upscale);
+    if (!(cfg->img_range > 0.f)) return gfail(IRA_ERR_ARG, "img_range must be positive");
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 3; m->scfg = *cfg;
+    m->cfg.inp_channels = m->cfg.out_channels = cfg->in_chans;
+    if (!sw_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
+    *out = m;
+    return IRA_OK;
+}
+
 int ira_model_destroy(ira_model_t* m) {
     if (!m) return IRA_OK;
     hipSetDevice(m->device);
@@ -845,17 +1122,19 @@ int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, flo
     if (B <= 0 || H <= 0 || W <= 0 || (m->arch == 0 && ((H & 7) || (W & 7))))
         return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
     const size_t n = (size_t)B * C * H * W;
-    int rc = ensure_scratch(m, 3 * al256(n * 4));
+    const int s = m->arch == 3 ? m->scfg.upscale : 1;             // SwinIR SR: the output is (B, C, H*s, W*s)
+    const size_t no = n * s * s;
+    int rc = ensure_scratch(m, al256(n * 4) + 2 * al256(no * 4));
     if (rc != IRA_OK) return rc;
     float* a = (float*)m->hs;                       // NCHW staging (in, then out)
-    float* nhwc_in = (float*)(m->hs + al256(n * 4));
-    float* nhwc_out = (float*)(m->hs + 2 * al256(n * 4));
+    float* nhwc_out = (float*)(m->hs + al256(no * 4));
+    float* nhwc_in = (float*)(m->hs + 2 * al256(no * 4));
     HIP_TRY(m, hipMemcpyAsync(a, in, n * 4, hipMemcpyHostToDevice, m->st));
     RUN(m, "layout", ira::launch_nchw_to_nhwc(m->st, a, nhwc_in, B, C, H, W));
     rc = forward_enqueue(m, nhwc_in, B, H, W, nhwc_out);
     if (rc != IRA_OK) return rc;
-    RUN(m, "layout", ira::launch_nhwc_to_nchw(m->st, nhwc_out, a, B, C, H, W));
-    HIP_TRY(m, hipMemcpyAsync(out, a, n * 4, hipMemcpyDeviceToHost, m->st));
+    RUN(m, "layout", ira::launch_nhwc_to_nchw(m->st, nhwc_out, a, B, C, H * s, W * s));
+    HIP_TRY(m, hipMemcpyAsync(out, a, no * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(m, hipStreamSynchronize(m->st));
     return IRA_OK;
 }
@@ -875,7 +1154,7 @@ int ira_restore_tiles_device(ira_model_t* m, const uint8_t* frame, int h, int w,
     if (!frame || !tiles_out) return m->fail(IRA_ERR_ARG, "ira_restore_tiles_device: NULL buffer");
     if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
     Plan p; std::string err;
-    int rc = make_plan(h, w, tile, overlap, p, err);
+    int rc = plan_for(m, h, w, tile, overlap, p, err);
     if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
     if (first_tile < 0 || n_tiles < 0 || first_tile + n_tiles > p.n_rows * p.n_cols)
         return m->fail(IRA_ERR_ARG, "tile range [%d,%d) outside the %dx%d plan", first_tile, first_tile + n_tiles, p.n_rows, p.n_cols);
@@ -890,9 +1169,9 @@ int ira_blend_tiles_device(ira_model_t* m, const float* tiles, int h, int w, int
     ENTER(m);
     if (!tiles || !out) return m->fail(IRA_ERR_ARG, "ira_blend_tiles_device: NULL buffer");
     Plan p; std::string err;
-    int rc = make_plan(h, w, tile, overlap, p, err);
+    int rc = plan_for(m, h, w, tile, overlap, p, err);
     if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
-    RUN(m, "tile_blend", ira::launch_blend(m->st, tiles, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw, p.n_rows, p.n_cols, out));
+    if ((rc = blend_enqueue(m, tiles, h, w, c, p, out)) != IRA_OK) return rc;
     HIP_TRY(m, hipStreamSynchronize(m->st));
     return IRA_OK;
 }
@@ -904,17 +1183,18 @@ int ira_restore_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int t
         std::lock_guard<std::mutex> lk(m->mu);
         if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_restore_u8: NULL buffer");
         if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
-        int rc = make_plan(h, w, tile, overlap, p, err);
+        int rc = plan_for(m, h, w, tile, overlap, p, err);
         if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
     }
     ENTER(m);
     const int nt = p.n_rows * p.n_cols;
     const size_t fbytes = (size_t)h * w * c;
-    const size_t tbytes = (size_t)nt * p.th * p.tw * c * 4;
+    const size_t obytes = fbytes * p.scale * p.scale;
+    const size_t tbytes = (size_t)nt * p.th * p.tw * c * 4 * p.scale * p.scale;
     uint8_t *fin = nullptr, *fout = nullptr; float* tiles = nullptr;
     auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tiles) hipFree(tiles); };
     hipError_t e;
-    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, fbytes)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, obytes)) != hipSuccess ||
         (e = hipMalloc((void**)&tiles, tbytes)) != hipSuccess) {
         cleanup();
         return m->fail(IRA_ERR_OOM, "ira_restore_u8: hipMalloc: %s", hipGetErrorString(e));
@@ -923,9 +1203,8 @@ int ira_restore_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int t
     do {
         if ((e = hipMemcpyAsync(fin, in, fbytes, hipMemcpyHostToDevice, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
         if ((rc = restore_tiles_enqueue(m, fin, h, w, c, p, 0, nt, tiles)) != IRA_OK) break;
-        rc = run(m, "tile_blend", [&]() { return ira::launch_blend(m->st, tiles, h, w, c, p.Hp, p.Wp, p.th, p.tw, p.sh, p.sw, p.n_rows, p.n_cols, fout); });
-        if (rc != IRA_OK) break;
-        if ((e = hipMemcpyAsync(out, fout, fbytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
+        if ((rc = blend_enqueue(m, tiles, h, w, c, p, fout)) != IRA_OK) break;
+        if ((e = hipMemcpyAsync(out, fout, obytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
         if ((e = hipStreamSynchronize(m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
     } while (0);
     if (rc != IRA_OK) hipStreamSynchronize(m->st);
@@ -1149,6 +1428,19 @@ int ira_op_naf_dw_sg(ira_model_t* m, const void* in, const float* w, const float
                      int W, int c, int* blocks_per_image) {
     if (blocks_per_image) *blocks_per_image = ira::naf_dw_sg_blocks(H, W, c);
     OP_BODY(m, "op", ira::launch_naf_dw_sg(m->st, in, w, bias, out, part, T, H, W, c));
+}
+
+int ira_op_swin_attn(ira_model_t* m, const void* qkv, const float* bias, void* out, int T, int H, int W, int heads, int ws, int shift) {
+    OP_BODY(m, "op", ira::launch_swin_attn(m->st, qkv, bias, out, T, H, W, heads, ws, shift));
+}
+
+int ira_op_ln_affine(ira_model_t* m, const float* x, const float* g, const float* b, float* y, long npx, int C, int Cp, float eps) {
+    OP_BODY(m, "op", ira::launch_ln_affine(m->st, x, g, b, y, npx, C, Cp, eps));
+}
+
+int ira_op_pw_kres_ex(ira_model_t* m, const void* x, int in_f32, int ln_mode, int K, const void* W, const float* bias, void* y,
+                      int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
+    OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act));
 }
 
 int ira_op_naf_tail(ira_model_t* m, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,

@@ -36,6 +36,17 @@ class IraNafnetConfig(C.Structure):
     ]
 
 
+SWINIR_MAX_LAYERS = 12
+
+
+class IraSwinirConfig(C.Structure):
+    _fields_ = [
+        ('upscale', C.c_int32), ('in_chans', C.c_int32), ('window_size', C.c_int32), ('img_range', C.c_float),
+        ('n_layers', C.c_int32), ('depths', C.c_int32 * SWINIR_MAX_LAYERS), ('embed_dim', C.c_int32),
+        ('num_heads', C.c_int32 * SWINIR_MAX_LAYERS), ('mlp_hidden', C.c_int32), ('upsampler', C.c_int32), ('resi_3conv', C.c_int32),
+    ]
+
+
 class IraDncnnConfig(C.Structure):
     _fields_ = [('in_nc', C.c_int32), ('nc', C.c_int32), ('nb', C.c_int32)]
 
@@ -49,6 +60,7 @@ SIGNATURES = {
     'ira_model_create': (_i, [_i, C.POINTER(IraConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_nafnet_create': (_i, [_i, C.POINTER(IraNafnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_dncnn_create': (_i, [_i, C.POINTER(IraDncnnConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_swinir_create': (_i, [_i, C.POINTER(IraSwinirConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_model_destroy': (_i, [_vp]),
     'ira_last_error': (C.c_char_p, [_vp]),
     'ira_sync': (_i, [_vp]),
@@ -80,6 +92,9 @@ SIGNATURES = {
     'ira_op_pw_kres_eps': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float]),
     'ira_op_naf_pw': (_i, [_vp, _i, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ira_op_naf_dw_sg': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _pi]),
+    'ira_op_swin_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    'ira_op_ln_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, C.c_float]),
+    'ira_op_pw_kres_ex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i]),
     'ira_op_naf_tail': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'ira_op_naf_sca': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i]),
 }

@@ -78,7 +78,8 @@ class _Backend:
         if x.ndim != 4:
             raise ValueError("expected (B,C,H,W)")
         B, Cc, H, W = x.shape
-        out = np.empty_like(x)
+        s = int(getattr(self, 'scale', 1))
+        out = np.empty((B, Cc, H * s, W * s), np.float32)
         self._ck(self._lib.ira_forward(self._h, x.ctypes.data, B, Cc, H, W, out.ctypes.data), 'ira_forward')
         return out
 
@@ -94,7 +95,8 @@ class _Backend:
         if img.dtype != np.uint8 or img.ndim != 3:
             raise ValueError("expected a uint8 (h,w,c) array")
         h, w, c = img.shape
-        out = np.empty_like(img)
+        s = int(getattr(self, 'scale', 1))
+        out = np.empty((h * s, w * s, c), np.uint8)
         rc = self._lib.ira_restore_u8(self._h, img.ctypes.data, h, w, c, int(tile) if tile else 0,
                                       int(tile_overlap), out.ctypes.data)
         self._ck(rc, 'ira_restore_u8')
@@ -189,3 +191,15 @@ class DnCNNBackend(_Backend):
         from .dncnn import pack_dncnn_blob, dncnn_cfg_struct
         self.cfg = cfg
         self._create(device, 'ira_dncnn_create', dncnn_cfg_struct(cfg), pack_dncnn_blob(state_dict, cfg), 'ira_dncnn_create')
+
+
+class SwinIRBackend(_Backend):
+    """One SwinIR on one MI355X (SwinIR/models/network_swinir.py).  ``forward``: float32 (B,C,H,W) ->
+    (B,C,H*upscale,W*upscale), any H, W.  ``restore``: the reference harness (SwinIR/inference.py:69-90,294-322: always-pad by
+    flip-concat, whole image or overlap-average tiler, clamp, round): uint8 (h,w,c) -> uint8 (h*s, w*s, c)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .swinir import pack_swinir_blob, swinir_cfg_struct
+        self.cfg = cfg
+        self.scale = cfg.upscale
+        self._create(device, 'ira_swinir_create', swinir_cfg_struct(cfg), pack_swinir_blob(state_dict, cfg), 'ira_swinir_create')

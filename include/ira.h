@@ -78,6 +78,23 @@ typedef struct ira_dncnn_config {
     int32_t nb;        /* 17 conv layers */
 } ira_dncnn_config;
 
+/* Constructor arguments of the reference SwinIR (SwinIR/models/network_swinir.py:646-653; task presets inference.py:136-200).
+ * ape = False, patch_norm = True, qkv_bias = True as in every reference preset. */
+#define IRA_SWINIR_MAX_LAYERS 12
+typedef struct ira_swinir_config {
+    int32_t upscale;                                  /* 1 (denoise / JPEG), 2, 4 */
+    int32_t in_chans;                                 /* 3 or 1 */
+    int32_t window_size;                              /* 8, or 7 for the JPEG models */
+    float   img_range;                                /* 1.0, or 255.0 for the JPEG models */
+    int32_t n_layers;                                 /* len(depths): 6 (M) or 9 (L) */
+    int32_t depths[IRA_SWINIR_MAX_LAYERS];            /* 6 each */
+    int32_t embed_dim;                                /* 180 (M), 240 (L) */
+    int32_t num_heads[IRA_SWINIR_MAX_LAYERS];         /* 6 / 8 each: head_dim 30 */
+    int32_t mlp_hidden;                               /* int(embed_dim * mlp_ratio) (:219), computed by the caller */
+    int32_t upsampler;                                /* 0 '' (conv_last + input skip), 1 'pixelshuffle', 2 'nearest+conv' */
+    int32_t resi_3conv;                               /* 0 '1conv', 1 '3conv' */
+} ira_swinir_config;
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
@@ -98,6 +115,10 @@ int ira_nafnet_create(int device, const ira_nafnet_config* cfg,
 /* DnCNN: blob from ira_amd/dncnn.py::pack_dncnn_blob; any H, W. */
 int ira_dncnn_create(int device, const ira_dncnn_config* cfg,
                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* SwinIR: blob from ira_amd/swinir.py::pack_swinir_blob.  ira_forward(_device) then take (B, in_chans, H, W) of any size
+ * (reflect-padded to the window inside, network_swinir.py:783-788) and return (B, in_chans, H*upscale, W*upscale). */
+int ira_swinir_create(int device, const ira_swinir_config* cfg,
+                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
 int ira_model_destroy(ira_model_t* model);
 
 /* Text of the last error on this handle (or, with model == NULL, of the last failed call that had
@@ -248,6 +269,22 @@ int ira_op_concat2(ira_model_t* m, const float* a_dev, int Ca, const float* b_de
 int ira_op_pw_kres_eps(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K,
                        const void* W_f16_dev, const float* bias_dev, void* y_f16_dev, int y_stride,
                        int n_store, int NB, int T, int P, float eps);
+
+/* ---- SwinIR kernels (network_swinir.py)
+ * (Shifted-)window attention, one call = roll(-shift) + window_partition + WindowAttention core + window_reverse + roll(+shift)
+ * (:114-145 inside :239-279): qkv fp16 (T,H,W,3*heads*32) laid out [q|k|v][head][32] (head_dim <= 32 zero-padded; q already
+ * scaled), bias fp32 [heads][64][64] = relative_position_bias_table[relative_position_index] as [query][key], out fp16
+ * (T,H,W,heads*32).  H, W multiples of ws; ws in {7, 8}; the shift mask of calculate_mask (:216-237) is computed in the kernel. */
+int ira_op_swin_attn(ira_model_t* m, const void* qkv_dev, const float* bias_dev, void* out_dev, int T, int H, int W, int heads,
+                     int ws, int shift);
+
+/* nn.LayerNorm over the first C of Cp channels, fp32 (npx, Cp) -> fp32; gain/bias fp32 [Cp] (zero beyond C). */
+int ira_op_ln_affine(ira_model_t* m, const float* x_dev, const float* g_dev, const float* b_dev, float* y_dev, long npx, int C,
+                     int Cp, float eps);
+
+/* ira_op_pw_kres with every option: eps, ln_n = number of real channels when K is zero-padded (0 = K), act 1 = exact-erf GELU. */
+int ira_op_pw_kres_ex(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K, const void* W_f16_dev, const float* bias_dev,
+                      void* y_f16_dev, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act);
 
 /* ---- NAFNet kernels (NAFNet_arch.py:158-326)
  * Pointwise contraction on an MFMA pixel grid of T x Hg x Wg pixels, W packed like every 1x1 here
