@@ -1,7 +1,7 @@
 """Agent-facing tool / registry API, source-compatible with the reference's
 
     AgenticIR/executor/tool.py:8-90            class Tool
-    AgenticIR/executor/multitask_tools.py:136-173   class Restormer(Tool)
+    AgenticIR/executor/multitask_tools.py:136-173   class Restormer(Tool);  :81-133 class SwinIR(Tool)
     AgenticIR/executor/__init__.py:24-169      class Executor, singleton ``executor``
 
 with the one difference that matters: ``Restormer._invoke`` runs the in-process HIP backend instead of
@@ -212,6 +212,101 @@ class Restormer(Tool):
         self._postprocess()
 
 
+# SwinIR tool: subtask -> (inference.py --task, {pretrained_on: checkpoint})   (multitask_tools.py:97-116)
+SWINIR_OPTS = {
+    'super_resolution': ('real_sr', {'gan': '003_realSR_BSRGAN_DFOWMFC_s64w8_SwinIR-L_x4_GAN.pth',
+                                     'psnr': '003_realSR_BSRGAN_DFOWMFC_s64w8_SwinIR-L_x4_PSNR.pth'}),
+    'denoising': ('color_dn', {'15': '005_colorDN_DFWB_s128w8_SwinIR-M_noise15.pth',
+                               '50': '005_colorDN_DFWB_s128w8_SwinIR-M_noise50.pth'}),
+    'jpeg_compression_artifact_removal': ('color_jpeg_car', {'40': '006_colorCAR_DFWB_s126w7_SwinIR-M_jpeg40.pth'}),
+}
+
+
+def default_swinir_loader(task: str, model_name: str, weight_dir: Optional[str] = None):
+    """``torch.load(model_path)[param_key_g]`` of SwinIR/inference.py:202-203 ('params_ema' for real_sr, :161).  Looks in
+    ``weight_dir`` or $IRA_SWINIR_WEIGHTS (the reference's ``SwinIR/model_zoo/swinir`` directory, multitask_tools.py:124)."""
+    from .swinir import PARAM_KEY
+    root = weight_dir or os.environ.get('IRA_SWINIR_WEIGHTS', '')
+    path = os.path.join(root, model_name)
+    if not (root and os.path.isfile(path)):
+        raise FileNotFoundError(f"SwinIR weights {model_name!r} not found in {root!r}; set IRA_SWINIR_WEIGHTS or pass a loader")
+    import torch
+    ckpt = torch.load(path, map_location='cpu')
+    key = PARAM_KEY.get(task, 'params')
+    return ckpt[key] if key in ckpt else ckpt
+
+
+class SwinIRCache:
+    """(task, checkpoint name) -> SwinIRBackend on one device, built on first use and kept for the life of the process."""
+
+    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
+                 backend_factory: Optional[Callable] = None):
+        self.device, self.weight_dir = device, weight_dir
+        self.loader = state_dict_loader or default_swinir_loader
+        self.factory = backend_factory
+        self.models: dict = {}
+
+    def get(self, task: str, model_name: str):
+        key = (task, model_name)
+        if key not in self.models:
+            from .swinir import task_config as swinir_task_config
+            cfg = swinir_task_config(task, scale=4, large_model=True)          # multitask_tools.py:128-132: --scale 4 --large_model
+            sd = self.loader(task, model_name, self.weight_dir)
+            if self.factory is not None:
+                self.models[key] = self.factory(cfg, sd, self.device)
+            else:
+                from .backend import SwinIRBackend
+                self.models[key] = SwinIRBackend(cfg, sd, device=self.device)
+        return self.models[key]
+
+    def close(self):
+        for be in self.models.values():
+            if hasattr(be, 'close'):
+                be.close()
+        self.models.clear()
+
+
+_default_swinir_cache: Optional[SwinIRCache] = None
+
+
+def default_swinir_cache() -> SwinIRCache:
+    global _default_swinir_cache
+    if _default_swinir_cache is None:
+        _default_swinir_cache = SwinIRCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+    return _default_swinir_cache
+
+
+class SwinIR(Tool):
+    """SwinIR tool for real SR (x4, SwinIR-L), colour denoising and JPEG artifact removal (multitask_tools.py:81-133),
+    in-process on the MI355X backend.  Like the reference tool it passes no ``--tile``: whole-image mode
+    (inference.py:295-297); ``tile`` / ``tile_overlap`` select the tiled mode of inference.py:298-320."""
+
+    def __init__(self, subtask: str, pretrained_on: str, cache: Optional[SwinIRCache] = None, tile: Optional[int] = None,
+                 tile_overlap: int = 32):
+        super().__init__(tool_name=f"swinir_{pretrained_on}", subtask=subtask, work_dir="SwinIR", script_rel_path="inference.py")
+        self.opt_task, opt_model_names = SWINIR_OPTS[canonical_subtask(subtask)]
+        self.model_name = opt_model_names[pretrained_on]
+        self._cache = cache
+        self.tile, self.tile_overlap = tile, tile_overlap
+
+    def _get_cmd_opts(self) -> list:
+        """Kept for introspection parity (multitask_tools.py:118-133); not used to spawn anything."""
+        opts = ["--task", self.opt_task, "--model_path", f"SwinIR/model_zoo/swinir/{self.model_name}",
+                "--folder_lq", getattr(self, 'input_dir', None), "--save_dir", getattr(self, 'output_dir', None)]
+        if canonical_subtask(self.subtask) == "super_resolution":
+            opts += ['--scale', '4', '--large_model']
+        return opts
+
+    def _invoke(self, *args) -> None:
+        self._preprocess()
+        be = (self._cache or default_swinir_cache()).get(self.opt_task, self.model_name)
+        src = sorted(Path(self.input_dir).glob('*'))[0]
+        img = read_image(src, gray=False)                    # the agent's three SwinIR tasks are colour (inference.py:236-260)
+        out = be.restore(img, tile=self.tile, tile_overlap=self.tile_overlap)
+        write_png(Path(self.output_dir) / 'output.png', out)   # inference.py:90 writes {imgname}.png; the tool renames it
+        self._postprocess()
+
+
 class Executor:
     """Registry of toolboxes (executor/__init__.py:24-94,161-169)."""
 
@@ -263,21 +358,31 @@ RESTORMER_SUBTASKS = {
 }
 
 
-def build_executor(cache: Optional[BackendCache] = None) -> Executor:
+def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None) -> Executor:
+    """The tools this backend provides, under the reference's subtask keys and in the reference's toolbox order
+    (executor/denoising/__init__.py:12-19, super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39)."""
     ex = Executor()
     for key, sub in RESTORMER_SUBTASKS.items():
         ex.register_subtask(key, [Restormer(subtask=sub, cache=cache)])
+    ex.toolbox_router['denoising'] = [SwinIR('denoising', '15', swinir_cache), SwinIR('denoising', '50', swinir_cache)] + ex.toolbox_router['denoising']
+    ex.register_subtask('super-resolution', [SwinIR('super_resolution', 'gan', swinir_cache), SwinIR('super_resolution', 'psnr', swinir_cache)])
+    ex.register_subtask('jpeg compression artifact removal', [SwinIR('jpeg_compression_artifact_removal', '40', swinir_cache)])
     return ex
 
 
-def install_into(reference_executor, cache: Optional[BackendCache] = None) -> int:
-    """Drop-in: replace every tool named 'restormer' in an existing (reference) executor's toolboxes by the
-    HIP-backed tool, leaving all other tools and the LLM orchestration untouched.  Returns the count."""
+def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None) -> int:
+    """Drop-in: replace every tool named 'restormer' or 'swinir_*' in an existing (reference) executor's toolboxes by
+    the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.  Returns the count."""
     n = 0
     for key, toolbox in reference_executor.toolbox_router.items():
         for i, tool in enumerate(toolbox):
-            if getattr(tool, 'tool_name', None) == 'restormer':
-                toolbox[i] = Restormer(subtask=canonical_subtask(getattr(tool, 'subtask', key)), cache=cache)
+            name = getattr(tool, 'tool_name', None) or ''
+            sub = canonical_subtask(getattr(tool, 'subtask', key))
+            if name == 'restormer':
+                toolbox[i] = Restormer(subtask=sub, cache=cache)
+                n += 1
+            elif name.startswith('swinir_') and sub in SWINIR_OPTS and name[7:] in SWINIR_OPTS[sub][1]:
+                toolbox[i] = SwinIR(subtask=sub, pretrained_on=name[7:], cache=swinir_cache)
                 n += 1
     return n
 

@@ -68,8 +68,11 @@ def test_subtask_to_task(subtask, task, cache):
 
 def test_executor_registry_and_directory_protocol(tmp_path, cache):
     ex = T.build_executor(cache)
-    assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining'}
-    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['restormer']
+    assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining', 'super-resolution',
+                           'jpeg compression artifact removal'}
+    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['swinir_15', 'swinir_50', 'restormer']     # reference order
+    assert [t.tool_name for t in ex.toolbox_router['super-resolution']] == ['swinir_gan', 'swinir_psnr']
+    assert [t.tool_name for t in ex.toolbox_router['jpeg compression artifact removal']] == ['swinir_40']
     root = tmp_path / 'task'
     (root / '0-img').mkdir(parents=True)
     img = _img(seed=3)
@@ -90,10 +93,44 @@ def test_install_into_reference_executor(cache):
     class RefExecutor:
         toolbox_router = {'denoising': [RefTool('xrestormer', 'denoising'), RefTool('restormer', 'denoising')],
                           'dehazing': [RefTool('maxim', 'dehazing')]}
+        toolbox_router['super-resolution'] = [RefTool('diffbir', 'super_resolution'), RefTool('swinir_gan', 'super_resolution')]
     n = T.install_into(RefExecutor, cache)
-    assert n == 1
+    assert n == 2
     tb = RefExecutor.toolbox_router['denoising']
     assert tb[0].tool_name == 'xrestormer' and isinstance(tb[1], T.Restormer) and tb[1].opt_task == 'Real_Denoising'
+    sr = RefExecutor.toolbox_router['super-resolution']
+    assert sr[0].tool_name == 'diffbir' and isinstance(sr[1], T.SwinIR) and sr[1].tool_name == 'swinir_gan' and sr[1].opt_task == 'real_sr'
+
+
+def test_swinir_tool_contract(tmp_path):
+    """multitask_tools.py:81-133: names, task / checkpoint mapping, x4 large model for SR, directory protocol."""
+    made = []
+
+    class FakeSR:
+        def __init__(self, cfg, sd, device):
+            self.cfg = cfg
+            made.append((cfg.upscale, cfg.embed_dim, cfg.upsampler, cfg.resi_connection, cfg.window_size, sd))
+
+        def restore(self, img, tile=None, tile_overlap=32):
+            s = self.cfg.upscale
+            return np.repeat(np.repeat(255 - img, s, 0), s, 1)
+    sc = T.SwinIRCache(state_dict_loader=lambda task, name, wd: (task, name), backend_factory=FakeSR)
+    tool = T.SwinIR('super_resolution', 'gan', cache=sc)
+    assert (tool.tool_name, tool.opt_task, tool.model_name) == ('swinir_gan', 'real_sr', '003_realSR_BSRGAN_DFOWMFC_s64w8_SwinIR-L_x4_GAN.pth')
+    inp, out = tmp_path / 'in', tmp_path / 'out'
+    inp.mkdir(); out.mkdir()
+    img = _img(10, 12)
+    Image.fromarray(img).save(inp / 'input.png')
+    tool(inp, out, silent=True)
+    assert os.listdir(out) == ['output.png']
+    assert np.asarray(Image.open(out / 'output.png')).shape == (40, 48, 3)
+    assert made == [(4, 240, 'nearest+conv', '3conv', 8, ('real_sr', '003_realSR_BSRGAN_DFOWMFC_s64w8_SwinIR-L_x4_GAN.pth'))]
+    j = T.SwinIR('jpeg_compression_artifact_removal', '40', cache=sc)
+    assert (j.tool_name, j.opt_task) == ('swinir_40', 'color_jpeg_car')
+    assert T.SwinIR('denoising', '50', cache=sc).model_name == '005_colorDN_DFWB_s128w8_SwinIR-M_noise50.pth'
+    assert '--large_model' in tool._get_cmd_opts() and '--large_model' not in j._get_cmd_opts()
+    with pytest.raises(KeyError):
+        T.SwinIR('denoising', '25')              # commented out in the reference (multitask_tools.py:106)
 
 
 def test_service_api(cache):
