@@ -219,10 +219,137 @@ def main_nafnet(args):
         dist.destroy_process_group()
 
 
+def main_swinir(args):
+    """BASELINE config 3 (as SURVEY 8d resolves it): SwinIR-L x4 real-SR (embed 240, 9 RSTB x 6 blocks, heads 8, window 8, '3conv',
+    'nearest+conv'), one 960x540 uint8 frame resident in HBM -> 3840x2160 uint8 in HBM through the reference harness
+    (always-pad to 544x968 by flip-concat, whole image as the agent's tool runs it: no --tile).  N > 1: independent replicas."""
+    import numpy as np
+    import torch
+    from ira_amd.backend import SwinIRBackend
+    from ira_amd.swinir import seeded_state_dict, task_config
+    from ira_amd.synth import synthetic_noisy_image
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cfg = task_config('real_sr', 4, True)
+    be = SwinIRBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
+    h, w, s, ws = args.height if args.height != 2160 else 540, args.width if args.width != 3840 else 960, cfg.upscale, cfg.window_size
+    _, noisy = synthetic_noisy_image(h, w, 3, sigma=10.0, seed=rank)
+    frame = torch.from_numpy(noisy).to(dev)
+    Hp, Wp = (h // ws + 1) * ws, (w // ws + 1) * ws
+    tiles = torch.empty((1, Hp * s, Wp * s, 3), dtype=torch.float32, device=dev)
+    out = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        be.restore_tiles_t(frame, h, w, 3, None, 32, 0, 1, tiles)
+        be.blend_tiles_t(tiles, h, w, 3, None, 32, out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        be.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    be.timer_start()
+    for _ in range(args.steps):
+        step()
+    dev_ms = be.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        be.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    step_s = elapsed / args.steps
+    mp_out = h * s * w * s / 1e6
+    in_px = Hp * Wp
+    net_bytes = 65.7e3 * 2.0 * in_px                 # SURVEY 8d: ~65.7k elements per input pixel (fp16 contract)
+    flops = 61.3e6 * in_px                           # SURVEY 8d: 61.3 MFLOP per input pixel
+    result = {
+        'metric': 'restored output megapixels/sec (SwinIR-L x4 real-SR, 960x540 -> 3840x2160)', 'value': round(world * mp_out / step_s, 3), 'unit': 'MP/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate + f32 token stream', 'data': 'synthetic',
+        'config': {'workload': f'SwinIR-L x4 (28.0M params, seeded weights), {w}x{h} uint8 frame -> {w * s}x{h * s}, padded to {Wp}x{Hp}, whole image, '
+                               f'one frame per GPU per step', 'frames_per_s': round(world / step_s, 3), 'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
+        'net_roofline': {'bound': 'mfma (SURVEY 8d: 467 FLOP/B under the fusion contract)', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
+                         'hbm_achieved_GBs': round(net_bytes / 1e9 / step_s, 1), 'hbm_frac': round(net_bytes / 1e9 / step_s / HBM_PEAK_GBS, 4),
+                         'algorithmic_TFLOP_per_step': round(flops / 1e12, 2), 'mfma_achieved_TFLOPs': round(flops / 1e12 / step_s, 1),
+                         'mfma_frac_of_dense_f16_peak': round(flops / 1e12 / step_s / MFMA_F16_PEAK_TFLOPS, 4)},
+    }
+    if world == 1 and not args.no_kernel_profile:
+        be.profile_enable(True)
+        step()
+        prof = be.profile()
+        be.profile_enable(False)
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f, indent=1, sort_keys=True)
+        tot = sum(v['ms'] for v in prof.values())
+        fam_tot = {}
+        for k, v in prof.items():
+            fam_tot[k.split('|')[0]] = fam_tot.get(k.split('|')[0], 0.0) + v['ms']
+        key = max(prof, key=lambda k: prof[k]['ms'])
+        C, hid, Kh = 256, 480, 256                   # padded embed_dim, mlp hidden, heads*32
+        # per launch of the dominant kernel: MFMA flops (fp32-equivalent, not counting the lo weight plane) and HBM bytes it must move
+        per_px = {'swin_ln_qkv': (2.0 * C * 3 * Kh, 4 * C + 2 * 3 * Kh), 'swin_window_attn': (4.0 * 64 * 32 * 8, 2 * 3 * Kh + 2 * Kh),
+                  'swin_proj_res': (2.0 * Kh * C, 2 * Kh + 8 * C), 'swin_ln_fc1_gelu': (2.0 * C * hid, 4 * C + 2 * hid),
+                  'swin_fc2_res': (2.0 * hid * C, 2 * hid + 8 * C)}.get(key.split('|')[0])
+        roof = {'bound': 'hbm', 'kernel': key, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
+        if per_px:
+            avg_ms = prof[key]['ms'] / prof[key]['launches']
+            gbs = per_px[1] * in_px / 1e9 / (avg_ms / 1e3)
+            roof.update({'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(avg_ms, 4),
+                         'launches_per_step': prof[key]['launches'], 'algorithmic_bytes_per_launch': int(per_px[1] * in_px),
+                         'mfma_TFLOPs': round(per_px[0] * in_px / 1e12 / (avg_ms / 1e3), 1), 'share_of_step': round(prof[key]['ms'] / tot, 4)})
+        result['roofline'] = roof
+        result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
+        result['kernel_ms_total_profiled'] = round(tot, 3)
+    else:
+        result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                              'note': 'per-kernel timing is collected at N=1 only'}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import swinir_oracle as S
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        S_ = 64
+        xc = torch.from_numpy(noisy[:S_, :S_]).float().div(255.).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            S.swinir_forward(xc, sd, cfg.to_dict())
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                S.swinir_forward(xc, sd, cfg.to_dict())
+            dt = (time.perf_counter() - t1) / reps
+        result['cpu_baseline'] = {'value': round(S_ * S_ * s * s / 1e6 / dt, 5), 'unit': 'MP/s (output)', 'cores': cores, 'kind': 'port',
+                                  'sample': f'oracle/swinir_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {S_}x{S_} input '
+                                            f'(-> {S_ * s}x{S_ * s}) after 1 warm-up ({dt:.2f} s each)'}
+    print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512'],
-                    help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = BASELINE configs[1]')
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4'],
+                    help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = configs[1]; swinir_x4 = configs[3]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
@@ -237,6 +364,8 @@ def main():
     args = ap.parse_args()
     if args.workload == 'nafnet512':
         return main_nafnet(args)
+    if args.workload == 'swinir_x4':
+        return main_swinir(args)
 
     import numpy as np
     import torch
