@@ -422,42 +422,51 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
     }
 }
 
-template <int NB, bool IN_F32>
+template <int NB, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0, int K0, const void* __restrict__ x1, int K1,
                                                      const f16* __restrict__ W, long w_tile_stride,
                                                      const float* __restrict__ bias, const float* resid, float* y,
                                                      int N, int T, int P) {
     // one weight "slab" = all NB row blocks of ONE k-step, hi and lo planes: F = 2*NB fragments of 1 KB.
     // Per-tile weights (attention apply): all four waves of a workgroup must be in the same tile, so the wave ->
-    // pixel map is per tile: chunks4 = ceil(chunks / 4) workgroups per tile.
+    // pixel map is per tile: ceil(chunks / (4*PG)) workgroups per tile.  PG = 32-pixel groups per wave: every weight
+    // fragment read from LDS feeds PG MFMAs (at PG = 1 the LDS read rate equals the MFMA rate: 1 KB per 32 cycles).
     constexpr int F = 2 * NB;
     constexpr int SH = (F + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* wl = (half8*)smem;                 // [2][F][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int chunks = (P + 31) >> 5;
-    const int wg_per_tile = (chunks + 3) >> 2;
+    const int wg_per_tile = (chunks + 4 * PG - 1) / (4 * PG);
     const int t = blockIdx.x / wg_per_tile;
-    const int ch = (blockIdx.x % wg_per_tile) * 4 + wave;
-    const bool live = ch < chunks;
-    const int p = (live ? ch : chunks - 1) * 32 + r;
-    const bool valid = live && p < P;
-    const long px = (long)t * P + (p < P ? p : P - 1);
+    const int ch0 = ((blockIdx.x % wg_per_tile) * 4 + wave) * PG;
+    bool valid[PG];
+    long px[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const int ch = ch0 + g;
+        const bool live = ch < chunks;
+        const int p = (live ? ch : chunks - 1) * 32 + r;
+        valid[g] = live && p < P;
+        px[g] = (long)t * P + (p < P ? p : P - 1);
+    }
     const int K = K0 + K1, KT = K >> 4;
 
-    f32x16 acc[NB];
+    f32x16 acc[PG][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        acc[nb] = zero16();
+        f32x16 init = zero16();
         if (bias != nullptr) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int n = 32 * nb + 16 * u + 8 * h + j;
-                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                    init[8 * u + j] = (n < N) ? bias[n] : 0.f;
                 }
         }
+#pragma unroll
+        for (int g = 0; g < PG; ++g) acc[g][nb] = init;
     }
     const f16* wt = W + (long)t * w_tile_stride + lane * 8;
     const long lo_off = (long)NB * KT * 512;
@@ -478,18 +487,25 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
             for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(s + 1, wave + 4 * i);
         }
         const int c0 = 16 * s;
-        half8 b;
-        if constexpr (IN_F32) {
-            const float* src = (c0 < K0) ? ((const float*)x0 + px * K0 + c0 + 8 * h) : ((const float*)x1 + px * K1 + (c0 - K0) + 8 * h);
-            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
-        } else {
-            const f16* src = (c0 < K0) ? ((const f16*)x0 + px * K0 + c0 + 8 * h) : ((const f16*)x1 + px * K1 + (c0 - K0) + 8 * h);
-            b = *(const half8*)src;
+        half8 b[PG];
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+            if constexpr (IN_F32) {
+                const float* src = (c0 < K0) ? ((const float*)x0 + px[g] * K0 + c0 + 8 * h) : ((const float*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+                b[g] = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+            } else {
+                const f16* src = (c0 < K0) ? ((const f16*)x0 + px[g] * K0 + c0 + 8 * h) : ((const f16*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+                b[g] = *(const half8*)src;
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[nb * 64 + lane], b, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(NB + nb) * 64 + lane], b, acc[nb], 0, 0, 0);
+            const half8 a = cur[nb * 64 + lane], al = cur[(NB + nb) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
+                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
+            }
         }
         if (s + 1 < KT) {
             half8* nxt = wl + ((s + 1) & 1) * F * 64;
@@ -498,24 +514,27 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
         }
         __syncthreads();
     }
-    if (!valid) return;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int g = 0; g < PG; ++g) {
+        if (!valid[g]) continue;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n0 = 32 * nb + 16 * u + 8 * h;
-            if (n0 + 8 <= N) {
-                f32x4 lo, hi;
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
-                if (resid != nullptr) {
-                    lo += *(const f32x4*)(resid + px * N + n0);
-                    hi += *(const f32x4*)(resid + px * N + n0 + 4);
+            for (int u = 0; u < 2; ++u) {
+                const int n0 = 32 * nb + 16 * u + 8 * h;
+                if (n0 + 8 <= N) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { lo[j] = acc[g][nb][8 * u + j]; hi[j] = acc[g][nb][8 * u + 4 + j]; }
+                    if (resid != nullptr) {
+                        lo += *(const f32x4*)(resid + px[g] * N + n0);
+                        hi += *(const f32x4*)(resid + px[g] * N + n0 + 4);
+                    }
+                    *(f32x4*)(y + px[g] * N + n0) = lo;
+                    *(f32x4*)(y + px[g] * N + n0 + 4) = hi;
                 }
-                *(f32x4*)(y + px * N + n0) = lo;
-                *(f32x4*)(y + px * N + n0 + 4) = hi;
             }
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1288,10 +1307,21 @@ static hipError_t pw_nres_lds_launch(hipStream_t st, const void* x0, int K0, con
                                      const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                      int T, int P) {
     const int chunks = (P + 31) / 32;
-    const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4))), block(256);
     const size_t smem = (size_t)2 * 2 * NB * 1024;
-    if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    else hipLaunchKernelGGL((k_pw_nres_lds<NB, false>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    static const int pg_env = env_int("IRA_NRES_LDS_PG", 0);
+    // two pixel groups per wave where the contraction is long enough to be MFMA/LDS-bound rather than HBM-bound
+    const bool pg2 = pg_env ? pg_env == 2 : (NB == 8 && (K0 + K1) >= 192 && chunks >= 8);   // measured: SwinIR-L fc2 46.4 -> 39.3 ms; no gain at NB <= 6
+    if constexpr (NB <= 8) {
+        if (pg2) {
+            const dim3 grid2((unsigned)((long)T * ((chunks + 7) / 8))), block2(256);
+            if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true, 2>), grid2, block2, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+            else hipLaunchKernelGGL((k_pw_nres_lds<NB, false, 2>), grid2, block2, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+            return hipGetLastError();
+        }
+    }
+    const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4))), block(256);
+    if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true, 1>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
+    else hipLaunchKernelGGL((k_pw_nres_lds<NB, false, 1>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
     return hipGetLastError();
 }
 
