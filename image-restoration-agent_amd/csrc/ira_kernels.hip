@@ -1281,6 +1281,7 @@ static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, i
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
                           const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
+    if (ln_n <= 0 || ln_n > K) ln_n = K;          // 0 = "all K channels are real"
     if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
     const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
     switch (K / 16) {

@@ -149,7 +149,7 @@ def test_benchmark_size_properties():
     y2 = be.forward(xb)
     assert np.isfinite(y1).all() and np.array_equal(y1, y2)
     assert np.array_equal(be.forward(xb[1:2])[0], y1[1])
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))      # the GPU box gives one-GPU jobs a 16-core share; more threads only spin
     sd = to_torch(seeded_state_dict(cfg, 0))
     with torch.no_grad():
         yo = O.restormer_forward(torch.from_numpy(xb[:1]), sd, cfg.to_dict()).numpy()

@@ -58,6 +58,7 @@ def split16(w):
 
 def close(a, b, rtol, atol_scale=1e-3):
     a = a.double(); b = b.double()
+    assert torch.isfinite(a).all(), f"{int((~torch.isfinite(a)).sum())}/{a.numel()} non-finite values in the result"
     atol = atol_scale * float(b.abs().max()) + 1e-6
     err = (a - b).abs()
     bad = err > (atol + rtol * b.abs())
