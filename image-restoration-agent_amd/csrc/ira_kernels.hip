@@ -480,39 +480,57 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
     for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[(wave + 4 * i) * 64 + lane] = stg[i];
     __syncthreads();
 
-    for (int s = 0; s < KT; ++s) {
-        const half8* cur = wl + (s & 1) * F * 64;
-        if (s + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(s + 1, wave + 4 * i);
-        }
+    // B (pixel) fragments are fetched BD k-steps ahead: a load issued in the k-step that uses it exposed one full memory
+    // latency per k-step (SQ_WAIT_ANY 72 % of wave cycles on the SwinIR fc2 shape), and loads cannot be hoisted over the
+    // barrier by the compiler
+    constexpr int BD = 4;
+    auto load_b = [&](int s, int g) -> half8 {
         const int c0 = 16 * s;
-        half8 b[PG];
+        if constexpr (IN_F32) {
+            const float* src = (c0 < K0) ? ((const float*)x0 + px[g] * K0 + c0 + 8 * h) : ((const float*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+            return cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else {
+            const f16* src = (c0 < K0) ? ((const f16*)x0 + px[g] * K0 + c0 + 8 * h) : ((const f16*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
+            return *(const half8*)src;
+        }
+    };
+    half8 bq[PG][BD];
 #pragma unroll
-        for (int g = 0; g < PG; ++g) {
-            if constexpr (IN_F32) {
-                const float* src = (c0 < K0) ? ((const float*)x0 + px[g] * K0 + c0 + 8 * h) : ((const float*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
-                b[g] = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
-            } else {
-                const f16* src = (c0 < K0) ? ((const f16*)x0 + px[g] * K0 + c0 + 8 * h) : ((const f16*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
-                b[g] = *(const half8*)src;
+    for (int j = 0; j < BD; ++j)
+        if (j < KT) {
+#pragma unroll
+            for (int g = 0; g < PG; ++g) bq[g][j] = load_b(j, g);
+        }
+    for (int s0 = 0; s0 < KT; s0 += BD) {
+#pragma unroll
+        for (int j = 0; j < BD; ++j) {
+            const int s = s0 + j;
+            if (s >= KT) break;
+            const half8* cur = wl + (s & 1) * F * 64;
+            if (s + 1 < KT) {
+#pragma unroll
+                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(s + 1, wave + 4 * i);
             }
-        }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const half8 a = cur[nb * 64 + lane], al = cur[(NB + nb) * 64 + lane];
+            for (int nb = 0; nb < NB; ++nb) {
+                const half8 a = cur[nb * 64 + lane], al = cur[(NB + nb) * 64 + lane];
 #pragma unroll
-            for (int g = 0; g < PG; ++g) {
-                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
-                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
+                for (int g = 0; g < PG; ++g) {
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[g][j], acc[g][nb], 0, 0, 0);
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[g][j], acc[g][nb], 0, 0, 0);
+                }
             }
-        }
-        if (s + 1 < KT) {
-            half8* nxt = wl + ((s + 1) & 1) * F * 64;
+            if (s + BD < KT) {
 #pragma unroll
-            for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+                for (int g = 0; g < PG; ++g) bq[g][j] = load_b(s + BD, g);
+            }
+            if (s + 1 < KT) {
+                half8* nxt = wl + ((s + 1) & 1) * F * 64;
+#pragma unroll
+                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
