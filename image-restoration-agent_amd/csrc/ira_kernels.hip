@@ -426,8 +426,12 @@ template <int NB, bool IN_F32, int PG>
 __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0, int K0, const void* __restrict__ x1, int K1,
                                                      const f16* __restrict__ W, long w_tile_stride,
                                                      const float* __restrict__ bias, const float* resid, float* y,
-                                                     int N, int T, int P) {
-    // one weight "slab" = all NB row blocks of ONE k-step, hi and lo planes: F = 2*NB fragments of 1 KB.
+                                                     int N, int T, int P, int NBtot) {
+    // NB = 32-row blocks per workgroup, starting at block blockIdx.y * NB of the matrix's NBtot (N-split: a smaller register
+    // tile lets three waves share a SIMD, which hides the per-k-step load / LDS-write / barrier phases that one wave per
+    // SIMD exposed: SwinIR-L fc2 at NB = 8 in one piece 36.6 ms per frame, as 2 x 4 blocks 34.2; the pixel operand is
+    // re-read once per split, from L2).
+    // one weight "slab" = the NB row blocks of ONE k-step, hi and lo planes: F = 2*NB fragments of 1 KB.
     // Per-tile weights (attention apply): all four waves of a workgroup must be in the same tile, so the wave ->
     // pixel map is per tile: ceil(chunks / (4*PG)) workgroups per tile.  PG = 32-pixel groups per wave: every weight
     // fragment read from LDS feeds PG MFMAs (at PG = 1 the LDS read rate equals the MFMA rate: 1 KB per 32 cycles).
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
         px[g] = (long)t * P + (p < P ? p : P - 1);
     }
     const int K = K0 + K1, KT = K >> 4;
+    const int nb0 = blockIdx.y * NB;
 
     f32x16 acc[PG][NB];
 #pragma unroll
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int n = 32 * nb + 16 * u + 8 * h + j;
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
                     init[8 * u + j] = (n < N) ? bias[n] : 0.f;
                 }
         }
@@ -469,9 +474,11 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
         for (int g = 0; g < PG; ++g) acc[g][nb] = init;
     }
     const f16* wt = W + (long)t * w_tile_stride + lane * 8;
-    const long lo_off = (long)NB * KT * 512;
-    auto gsrc = [&](int s, int f) -> const half8* {     // f < NB: hi plane block f, else lo plane block f-NB
-        return (const half8*)(wt + (f < NB ? 0 : lo_off) + ((long)(f < NB ? f : f - NB) * KT + s) * 512);
+    const long lo_off = (long)NBtot * KT * 512;
+    auto gsrc = [&](int s, int f) -> const half8* {     // f < NB: hi plane block nb0+f, else lo plane block nb0+f-NB
+        int nb = nb0 + (f < NB ? f : f - NB);
+        if (nb >= NBtot) nb = NBtot - 1;                 // partial last split: staged, never stored
+        return (const half8*)(wt + (f < NB ? 0 : lo_off) + ((long)nb * KT + s) * 512);
     };
     half8 stg[SH];
 #pragma unroll
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
     // B (pixel) fragments are fetched BD k-steps ahead: a load issued in the k-step that uses it exposed one full memory
     // latency per k-step (SQ_WAIT_ANY 72 % of wave cycles on the SwinIR fc2 shape), and loads cannot be hoisted over the
     // barrier by the compiler
-    constexpr int BD = 4;
+    constexpr int BD = (NB <= 3 && PG == 1) ? 4 : 1;      // deeper only where the registers are free (<= 152 -> 3 waves per SIMD)
     auto load_b = [&](int s, int g) -> half8 {
         const int c0 = 16 * s;
         if constexpr (IN_F32) {
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(256) void k_pw_nres_lds(const void* __restrict__ x0
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n0 = 32 * nb + 16 * u + 8 * h;
+                const int n0 = 32 * (nb0 + nb) + 16 * u + 8 * h;
                 if (n0 + 8 <= N) {
                     f32x4 lo, hi;
 #pragma unroll
@@ -1321,27 +1328,32 @@ static hipError_t pw_nres_launch(hipStream_t st, const void* x0, int K0, const v
     return hipGetLastError();
 }
 
+template <int NBW, int PG>
+static hipError_t pw_nres_lds_launch_w(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
+                                       const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
+                                       int T, int P, int NBtot) {
+    const int chunks = (P + 31) / 32;
+    const size_t smem = (size_t)2 * 2 * NBW * 1024;
+    const dim3 grid((unsigned)((long)T * ((chunks + 4 * PG - 1) / (4 * PG))), (unsigned)((NBtot + NBW - 1) / NBW)), block(256);
+    if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NBW, true, PG>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P, NBtot);
+    else hipLaunchKernelGGL((k_pw_nres_lds<NBW, false, PG>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P, NBtot);
+    return hipGetLastError();
+}
+
 template <int NB>
 static hipError_t pw_nres_lds_launch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                      const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                      int T, int P) {
-    const int chunks = (P + 31) / 32;
-    const size_t smem = (size_t)2 * 2 * NB * 1024;
-    static const int pg_env = env_int("IRA_NRES_LDS_PG", 0);
-    // two pixel groups per wave where the contraction is long enough to be MFMA/LDS-bound rather than HBM-bound
-    const bool pg2 = pg_env ? pg_env == 2 : (NB == 8 && (K0 + K1) >= 192 && chunks >= 8);   // measured: SwinIR-L fc2 46.4 -> 39.3 ms; no gain at NB <= 6
-    if constexpr (NB <= 8) {
-        if (pg2) {
-            const dim3 grid2((unsigned)((long)T * ((chunks + 7) / 8))), block2(256);
-            if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true, 2>), grid2, block2, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-            else hipLaunchKernelGGL((k_pw_nres_lds<NB, false, 2>), grid2, block2, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-            return hipGetLastError();
-        }
+    static const int nbw_env = env_int("IRA_NRES_NBW", 0);     // 0 = rule below; otherwise the cap on blocks per workgroup
+    // measured per 4K / SwinIR frame: NB = 8 as 2 x 4 blocks 62.7 -> 34-37 ms (fc2); NB = 6 as 2 x 3 and NB = 12 as 3 x 4 lose (pout 10.2 -> 11.6)
+    const int cap = nbw_env > 0 ? nbw_env : (NB == 8 ? 4 : 16);
+    if constexpr (NB > 4) {
+        if (cap <= 2) return pw_nres_lds_launch_w<2, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P, NB);
+        if (cap == 3 || (cap == 4 && NB % 4 != 0 && NB % 3 == 0))
+            return pw_nres_lds_launch_w<3, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P, NB);
+        if (cap == 4) return pw_nres_lds_launch_w<4, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P, NB);
     }
-    const dim3 grid((unsigned)((long)T * ((chunks + 3) / 4))), block(256);
-    if (in_f32) hipLaunchKernelGGL((k_pw_nres_lds<NB, true, 1>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    else hipLaunchKernelGGL((k_pw_nres_lds<NB, false, 1>), grid, block, smem, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    return hipGetLastError();
+    return pw_nres_lds_launch_w<NB, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P, NB);
 }
 
 template <int NB>
