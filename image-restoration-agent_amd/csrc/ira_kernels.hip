@@ -303,19 +303,19 @@ __global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, in
 // L2-bandwidth bound at ~0.5 TB/s of useful traffic.  Here the 4 waves of a workgroup stage every weight block in
 // LDS cooperatively (each wave fetches a quarter, one block ahead, through registers) and all read it back with
 // conflict-free ds_read_b128: 4x less L2 traffic.  Waves never exit early (barriers): out-of-range waves clamp.
-template <int KS, int LN, bool IN_F32>
-__global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xin, const f16* __restrict__ W,
+template <int KS, int LN, bool IN_F32, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void k_pw_kres_lds(const void* __restrict__ xin, const f16* __restrict__ W,
                                                      const float* __restrict__ bias, f16* __restrict__ y,
                                                      int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     constexpr int K = KS * 16;
     constexpr int F = 2 * KS;                 // fragments (1 KB each) per 32-row weight block: hi plane then lo plane
-    constexpr int SH = F / 4;                 // fragments each wave stages per block
+    constexpr int SH = (F + NW - 1) / NW;     // fragments each of the NW waves stages per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* wl = (half8*)smem;                 // [2][F][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int chunks = (P + 31) >> 5;
     const long total = (long)T * chunks;
-    long wv = (long)blockIdx.x * 4 + wave;
+    long wv = (long)blockIdx.x * NW + wave;
     const bool live = wv < total;
     if (!live) wv = total - 1;
     const int t = (int)(wv / chunks);
@@ -374,16 +374,16 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
     const int nb_lo = blockIdx.y * nb_per, nb_hi = min(NB, nb_lo + nb_per);
     half8 stg[SH];
 #pragma unroll
-    for (int i = 0; i < SH; ++i) stg[i] = *gsrc(nb_lo, wave + 4 * i);
+    for (int i = 0; i < SH; ++i) if (wave + NW * i < F) stg[i] = *gsrc(nb_lo, wave + NW * i);
 #pragma unroll
-    for (int i = 0; i < SH; ++i) wl[(wave + 4 * i) * 64 + lane] = stg[i];
+    for (int i = 0; i < SH; ++i) if (wave + NW * i < F) wl[(wave + NW * i) * 64 + lane] = stg[i];
     __syncthreads();
 
     for (int nb = nb_lo; nb < nb_hi; ++nb) {
         const half8* cur = wl + ((nb - nb_lo) & 1) * F * 64;
         if (nb + 1 < nb_hi) {
 #pragma unroll
-            for (int i = 0; i < SH; ++i) stg[i] = *gsrc(nb + 1, wave + 4 * i);     // prefetch, issued before the stores below
+            for (int i = 0; i < SH; ++i) if (wave + NW * i < F) stg[i] = *gsrc(nb + 1, wave + NW * i);     // prefetch, issued before the stores below
         }
         f32x16 acc;
         if (bias != nullptr) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_pw_kres_lds(const void* __restrict__ xi
         if (nb + 1 < nb_hi) {
             half8* nxt = wl + ((nb + 1 - nb_lo) & 1) * F * 64;
 #pragma unroll
-            for (int i = 0; i < SH; ++i) nxt[(wave + 4 * i) * 64 + lane] = stg[i];
+            for (int i = 0; i < SH; ++i) if (wave + NW * i < F) nxt[(wave + NW * i) * 64 + lane] = stg[i];
         }
         __syncthreads();
     }
@@ -1263,20 +1263,20 @@ static hipError_t pw_kres_launch(hipStream_t st, const void* x, bool in_f32, int
     return hipGetLastError();
 }
 
-template <int KS>
-static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
-                                     f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
+template <int KS, int NW, int MINW>
+static hipError_t pw_kres_lds_launch_nw(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
+                                        f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
     const long waves = (long)T * ((P + 31) / 32);
-    const long wgs = (waves + 3) / 4;
+    const long wgs = (waves + NW - 1) / NW;
     int splits = 1;
     if (wgs < 512 && NB >= 8) splits = (int)std::min<long>(NB / 4, (1024 + wgs - 1) / wgs);
-    const dim3 grid(grid1d(waves, 4), splits), block(256);
+    const dim3 grid((unsigned)wgs, splits), block(64 * NW);
     const size_t smem = (size_t)2 * 2 * KS * 1024;
 #define IRA_KL(LN_, F32_)                                                                                               \
     do {                                                                                                                \
         static bool done_ = false;                                                                                      \
-        if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
-        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);      \
+        if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_, NW, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
+        hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_, NW, MINW>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);      \
     } while (0)
     if (in_f32) {
         if (ln == 0) IRA_KL(0, true); else if (ln == 1) IRA_KL(1, true); else IRA_KL(2, true);
@@ -1286,6 +1286,19 @@ static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32,
     }
 #undef IRA_KL
     return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t pw_kres_lds_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias,
+                                     f16* y, int ys, int ns, int NB, int T, int P, float eps, int ln_n, int act) {
+    static const int occ_env = env_int("IRA_KRES_OCC", 1);
+    if constexpr (KS == 12) {   // 48 KB per workgroup: three workgroups per CU if the wave fits 170 registers
+        if (occ_env) return pw_kres_lds_launch_nw<KS, 4, 3>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);
+    }
+    if constexpr (KS == 24) {   // 96 KB per workgroup = one per CU: eight waves share it (two per SIMD instead of one)
+        if (occ_env) return pw_kres_lds_launch_nw<KS, 8, 2>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);
+    }
+    return pw_kres_lds_launch_nw<KS, 4, 1>(st, x, in_f32, ln, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);
 }
 
 template <int KS>
