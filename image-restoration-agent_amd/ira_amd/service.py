@@ -87,8 +87,25 @@ def restore(image, task: str = 'Real_Denoising', tool: str = 'restormer', tile=N
     """restore(image, task=...) of BASELINE.json: uint8 (h,w,c) ndarray (or PIL image / path / encoded bytes)
     -> restored uint8 ndarray.  ``task`` is a reference task name (demo.py:31-36) or an agent subtask
     ('denoising', 'motion deblurring', ...: multitask_tools.py:151-156)."""
+    if tool.startswith('swinir_'):
+        # the agent's SwinIR tools (multitask_tools.py:81-133): task = the subtask, tool = 'swinir_15' | '_50' | '_gan' | '_psnr' | '_40'
+        from .tools import SWINIR_OPTS, default_swinir_cache, read_image
+        sub = canonical_subtask(task)
+        if sub not in SWINIR_OPTS or tool[7:] not in SWINIR_OPTS[sub][1]:
+            raise ValueError(f"tool {tool!r} does not handle task {task!r}")
+        opt_task, names = SWINIR_OPTS[sub]
+        if isinstance(image, (bytes, bytearray)):
+            img = decode_image(bytes(image), False)
+        elif isinstance(image, (str, os.PathLike)):
+            img = read_image(image, False)
+        elif isinstance(image, np.ndarray):
+            img = image
+        else:
+            img = np.asarray(image.convert('RGB'), dtype=np.uint8)
+        be = (cache or default_swinir_cache()).get(opt_task, names[tool[7:]])
+        return be.restore(np.ascontiguousarray(img, dtype=np.uint8), tile=tile, tile_overlap=tile_overlap)
     if tool != 'restormer':
-        raise ValueError(f"tool {tool!r} is not provided by the HIP backend (only 'restormer')")
+        raise ValueError(f"tool {tool!r} is not provided by the HIP backend ('restormer', 'swinir_15|50|gan|psnr|40')")
     if task not in SUPPORTED_TASKS:
         key = canonical_subtask(task)
         if key not in SUBTASK_TO_TASK:

@@ -161,6 +161,18 @@ def test_restore_alias(cache):
         S.restore(img, task='colorize', cache=cache)
     with pytest.raises(ValueError):
         S.restore(img, tool='swinir', cache=cache)
+    with pytest.raises(ValueError):
+        S.restore(img, task='deraining', tool='swinir_gan', cache=cache)       # SwinIR has no deraining model
+
+    class FakeSR:
+        def __init__(self, cfg, sd, device):
+            self.cfg = cfg
+
+        def restore(self, im, tile=None, tile_overlap=32):
+            return np.repeat(np.repeat(im, self.cfg.upscale, 0), self.cfg.upscale, 1)
+    sc = T.SwinIRCache(state_dict_loader=lambda task, name, wd: {}, backend_factory=FakeSR)
+    assert S.restore(img, task='super-resolution', tool='swinir_psnr', cache=sc).shape == (36, 32, 3)
+    assert S.restore(img, task='denoising', tool='swinir_50', cache=sc).shape == (9, 8, 3)
 
 
 def test_task_table_matches_reference():
@@ -202,3 +214,35 @@ def test_product_path_fails_loudly_without_gpu():
     cfg = reduced_config()
     with pytest.raises(IraError):
         RestormerBackend(cfg, seeded_state_dict(cfg, 0))
+
+
+def test_swinir_service_api():
+    """model_serving.py (SwinIR): define_model presets, the load_model cache key, process_image's BGR float contract."""
+    from ira_amd import swinir_service as SS
+    cfg, key = SS.define_model('real_sr', scale=4, large_model=True)
+    assert (cfg.embed_dim, len(cfg.depths), cfg.upsampler, cfg.resi_connection, key) == (240, 9, 'nearest+conv', '3conv', 'params_ema')
+    cfg, key = SS.define_model('color_jpeg_car')
+    assert (cfg.window_size, cfg.img_range, cfg.img_size, key) == (7, 255., 126, 'params')
+    assert SS.define_model('classical_sr', scale=2)[0].img_size == 48            # :45
+    with pytest.raises(ValueError):
+        SS.define_model('nope')
+
+    class Fake:
+        def __init__(self, cfg, sd, device):
+            self.cfg, self.sd = cfg, sd
+
+        def restore(self, img, tile=None, tile_overlap=32):
+            s = self.cfg.upscale
+            return np.repeat(np.repeat(img, s, 0), s, 1)
+    svc = SS.SwinIRService(model_path='/w/x.pth', state_dict_loader=lambda path, key: (path, key), backend_factory=Fake)
+    m, err = svc.load_model('real_sr', scale=4, large_model=True)
+    assert err is None and m.sd == ('/w/x.pth', 'params_ema') and list(svc.models) == ['real_sr_4_15_40_True']
+    assert svc.load_model('real_sr', scale=4, large_model=True)[0] is m
+    bgr = _img(6, 5)[:, :, ::-1].astype(np.float32) / 255.
+    out = svc.process_image(bgr, m, 4, 8)
+    assert out.dtype == np.uint8 and out.shape == (24, 20, 3)
+    assert np.array_equal(out[::4, ::4], np.rint(bgr * 255).astype(np.uint8))     # BGR in, BGR out
+    with pytest.raises(ValueError):
+        svc.process_image(bgr, m, 2, 8)
+    miss = SS.SwinIRService(model_path='/nonexistent.pth')
+    assert miss.load_model('color_dn')[1].startswith('Model file not found')
