@@ -1148,6 +1148,18 @@ int ira_tile_plan(int h, int w, int tile, int overlap, int* Hp, int* Wp, int* th
     return IRA_OK;
 }
 
+int ira_model_tile_plan(ira_model_t* m, int h, int w, int tile, int overlap, int* Hp, int* Wp, int* th, int* tw, int* n_rows,
+                        int* n_cols, int* scale) {
+    if (!m) return gfail(IRA_ERR_ARG, "ira_model_tile_plan: model is NULL");
+    std::lock_guard<std::mutex> lk(m->mu);
+    Plan p; std::string err;
+    int rc = plan_for(m, h, w, tile, overlap, p, err);
+    if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
+    if (Hp) *Hp = p.Hp; if (Wp) *Wp = p.Wp; if (th) *th = p.th; if (tw) *tw = p.tw;
+    if (n_rows) *n_rows = p.n_rows; if (n_cols) *n_cols = p.n_cols; if (scale) *scale = p.scale;
+    return IRA_OK;
+}
+
 int ira_restore_tiles_device(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap,
                              int first_tile, int n_tiles, float* tiles_out) {
     ENTER(m);

@@ -67,6 +67,7 @@ SIGNATURES = {
     'ira_forward': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'ira_forward_device': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ira_tile_plan': (_i, [_i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi]),
+    'ira_model_tile_plan': (_i, [_vp, _i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi, _pi]),
     'ira_restore_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ira_restore_padcrop_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ira_restore_tiles_device': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

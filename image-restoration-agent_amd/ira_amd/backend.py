@@ -102,6 +102,13 @@ class _Backend:
         self._ck(rc, 'ira_restore_u8')
         return out
 
+    def plan(self, h: int, w: int, tile, overlap: int):
+        """(Hp, Wp, tile_h, tile_w, n_rows, n_cols, scale) of this model's harness (SwinIR: always-pad rule and upscale)."""
+        v = [C.c_int(0) for _ in range(7)]
+        rc = self._lib.ira_model_tile_plan(self._h, h, w, int(tile) if tile else 0, int(overlap), *[C.byref(x) for x in v])
+        self._ck(rc, 'ira_model_tile_plan')
+        return tuple(x.value for x in v)
+
     def restore_padcrop(self, img_u8: np.ndarray, tile_size=None, tile_pad: int = 32, padding_size: int = 64) -> np.ndarray:
         """The reference's other tiler (xrestormer_model.py:53-136: reflect-pad to ``padding_size``, non-overlapping
         ``tile_size`` cores with a ``tile_pad`` halo, crop): uint8 (h,w,c) -> uint8 (h,w,c)."""

@@ -33,7 +33,9 @@ class TileParallelRestorer:
     def __init__(self, backend, rank: int = 0, world: int = 1, group=None, plan_fn=None):
         self.be = backend
         self.rank, self.world, self.group = rank, world, group
-        self.plan_fn = plan_fn or _capi.tile_plan
+        # the plan of the model's own harness (SwinIR: always-pad rule, outputs scaled by `upscale`); plan functions may
+        # return 6 values (scale 1) or 7
+        self.plan_fn = plan_fn or getattr(backend, 'plan', None) or _capi.tile_plan
         self._bufs = {}
 
     def _buffers(self, key, n_local, n_all, th, tw, c, device):
@@ -45,12 +47,14 @@ class TileParallelRestorer:
 
     def restore_frame(self, frame_u8: torch.Tensor, tile, overlap: int = 32, out: torch.Tensor | None = None):
         """frame_u8: (h,w,c) uint8 tensor resident on this rank's device (every rank holds the frame).
-        Returns the restored (h,w,c) uint8 tensor (identical on every rank)."""
+        Returns the restored (h*scale, w*scale, c) uint8 tensor (identical on every rank)."""
         h, w, c = frame_u8.shape
-        Hp, Wp, th, tw, n_rows, n_cols = self.plan_fn(h, w, tile, overlap)
+        plan = tuple(self.plan_fn(h, w, tile, overlap))
+        Hp, Wp, th, tw, n_rows, n_cols = plan[:6]
+        s = plan[6] if len(plan) > 6 else 1
         nt = n_rows * n_cols
         first, count, chunk = block_partition(nt, self.world, self.rank)
-        local, allt = self._buffers((h, w, c, tile, overlap), chunk, chunk * self.world, th, tw, c, frame_u8.device)
+        local, allt = self._buffers((h, w, c, tile, overlap), chunk, chunk * self.world, th * s, tw * s, c, frame_u8.device)
         if count > 0:
             self.be.restore_tiles_t(frame_u8, h, w, c, tile, overlap, first, count, local)
         if self.world > 1:
@@ -60,6 +64,6 @@ class TileParallelRestorer:
             if frame_u8.is_cuda:
                 torch.cuda.synchronize(frame_u8.device)     # RCCL stream -> visible to the library stream
         if out is None:
-            out = torch.empty_like(frame_u8)
+            out = torch.empty((h * s, w * s, c), dtype=torch.uint8, device=frame_u8.device)
         self.be.blend_tiles_t(allt, h, w, c, tile, overlap, out)
         return out

@@ -164,6 +164,12 @@ int ira_restore_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h, int w,
 int ira_restore_padcrop_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h, int w, int c,
                            int tile_size, int tile_pad, int padding_size, uint8_t* out_hwc_host);
 
+/* The tiling plan of THIS model's harness: ira_tile_plan's rule for Restormer / NAFNet / DnCNN handles; for a SwinIR handle the
+ * always-pad-to-(h // ws + 1) * ws rule of SwinIR/inference.py:76-80,294-310, with `scale` = upscale (tiles_out of
+ * ira_restore_tiles_device are then (n, tile_h*scale, tile_w*scale, c) and ira_blend_tiles_device writes (h*scale, w*scale, c)). */
+int ira_model_tile_plan(ira_model_t* model, int h, int w, int tile, int overlap,
+                        int* Hp, int* Wp, int* tile_h, int* tile_w, int* n_rows, int* n_cols, int* scale);
+
 /* Sharded form for one-process-per-GPU tile parallelism.  All pointers are device
  * memory.  frame: uint8 (h,w,c), unpadded.  Runs tiles [first_tile, first_tile+n_tiles) of the
  * row-major tile list through the network and writes them, float32 NHWC (n_tiles,tile_h,tile_w,c),

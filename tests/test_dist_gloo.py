@@ -55,19 +55,66 @@ class CpuTileBackend:
         out.copy_(torch.from_numpy(O.img_as_ubyte(torch.clamp(E / Wt, 0, 1)[:h, :w].numpy())))
 
 
+def sw_plan(h, w, tile, overlap, ws=8, scale=2):
+    """SwinIR harness plan (SwinIR/inference.py:76-80,294-310) with the 7th value = scale, as ira_model_tile_plan returns it."""
+    Hp, Wp = (h // ws + 1) * ws, (w // ws + 1) * ws
+    if not tile:
+        return Hp, Wp, Hp, Wp, 1, 1, scale
+    t = min(tile, Hp, Wp)
+    s = t - overlap
+    return Hp, Wp, t, t, len(O.tile_index_list(Hp, t, s)), len(O.tile_index_list(Wp, t, s)), scale
+
+
+def fake_sr(t):                       # (n, th, tw, c) -> (n, 2th, 2tw, c), tile-dependent like a real network
+    up = t.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    return up * 0.8 + 0.1 * t.mean(dim=(1, 2, 3), keepdim=True)
+
+
+class CpuSrBackend:
+    """SwinIR-harness stand-in: always-pad by flip-concat, x2 outputs, overlap average on the scaled grid."""
+
+    def _geom(self, h, w, tile, overlap):
+        Hp, Wp, th, tw, nr, nc, s = sw_plan(h, w, tile, overlap)
+        hi = O.tile_index_list(Hp, th, th - overlap) if tile else [0]
+        wi = O.tile_index_list(Wp, tw, tw - overlap) if tile else [0]
+        return Hp, Wp, th, tw, hi, wi, s
+
+    def restore_tiles_t(self, frame, h, w, c, tile, overlap, first, n, out):
+        from oracle.swinir_oracle import harness_pad
+        Hp, Wp, th, tw, hi, wi, s = self._geom(h, w, tile, overlap)
+        x = harness_pad(frame.float().div(255.).permute(2, 0, 1).unsqueeze(0), 8)[0].permute(1, 2, 0)
+        origins = [(y, xx) for y in hi for xx in wi][first:first + n]
+        out[:n] = fake_sr(torch.stack([x[y:y + th, xx:xx + tw] for y, xx in origins]))
+
+    def blend_tiles_t(self, tiles, h, w, c, tile, overlap, out):
+        Hp, Wp, th, tw, hi, wi, s = self._geom(h, w, tile, overlap)
+        E = torch.zeros(Hp * s, Wp * s, c); Wt = torch.zeros(Hp * s, Wp * s, c)
+        k = 0
+        for y in hi:
+            for xx in wi:
+                E[y * s:(y + th) * s, xx * s:(xx + tw) * s] += tiles[k]; Wt[y * s:(y + th) * s, xx * s:(xx + tw) * s] += 1; k += 1
+        out.copy_(torch.from_numpy(O.img_as_ubyte(torch.clamp(E / Wt, 0, 1)[:h * s, :w * s].numpy())))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, h, w, tile, overlap, q):
+def _make(kind, rank, world):
+    if kind == 'sr':
+        return TileParallelRestorer(CpuSrBackend(), rank, world, plan_fn=sw_plan)
+    return TileParallelRestorer(CpuTileBackend(), rank, world, plan_fn=py_plan)
+
+
+def _worker(rank, world, port, h, w, tile, overlap, q, kind='rst'):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     _, noisy = O.synthetic_noisy_image(h, w, 3, seed=5)
-    rst = TileParallelRestorer(CpuTileBackend(), rank, world, plan_fn=py_plan)
+    rst = _make(kind, rank, world)
     out = rst.restore_frame(torch.from_numpy(noisy), tile, overlap)
     out2 = rst.restore_frame(torch.from_numpy(noisy), tile, overlap)     # buffers are reused across frames
     assert torch.equal(out, out2)
@@ -76,14 +123,17 @@ def _worker(rank, world, port, h, w, tile, overlap, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,h,w,tile,overlap', [(2, 150, 203, 64, 16), (3, 97, 130, 48, 8), (2, 70, 100, 512, 32)])
-def test_tile_parallel_matches_single_process(world, h, w, tile, overlap):
+@pytest.mark.parametrize('world,h,w,tile,overlap,kind', [(2, 150, 203, 64, 16, 'rst'), (3, 97, 130, 48, 8, 'rst'), (2, 70, 100, 512, 32, 'rst'),
+                                                          (2, 61, 90, 32, 8, 'sr'), (3, 64, 64, 24, 8, 'sr')])
+def test_tile_parallel_matches_single_process(world, h, w, tile, overlap, kind):
+    """'rst': Restormer harness (pad to 8 if needed, scale 1); 'sr': SwinIR harness (always-pad flip-concat, x2 outputs)."""
     _, noisy = O.synthetic_noisy_image(h, w, 3, seed=5)
-    single = TileParallelRestorer(CpuTileBackend(), 0, 1, plan_fn=py_plan).restore_frame(torch.from_numpy(noisy), tile, overlap).numpy()
+    single = _make(kind, 0, 1).restore_frame(torch.from_numpy(noisy), tile, overlap).numpy()
+    assert single.shape == ((2 * h, 2 * w, 3) if kind == 'sr' else (h, w, 3))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, tile, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, tile, overlap, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=120) for _ in range(world))

@@ -168,6 +168,17 @@ def test_harness_matches_oracle(name, cfgf, seed, h, w, tile, ov):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.05 and d <= 1e-3
 
 
+def test_tile_parallel_restorer_world1_scaled():
+    """ira_amd/dist.py on the SwinIR harness (model-aware plan, x4 tiles): world 1 equals the one-call harness."""
+    from ira_amd.dist import TileParallelRestorer
+    cfg = reduced_swinir_config(upscale=4, upsampler='nearest+conv', resi_connection='3conv', embed_dim=64, num_heads=[2, 2])
+    be = backend(cfg, 5)
+    _, img = synthetic_noisy_image(37, 52, 3, sigma=25.0, seed=8)
+    assert be.plan(37, 52, 16, 8) == (40, 56, 16, 16, 4, 6, 4)
+    out = TileParallelRestorer(be, 0, 1).restore_frame(torch.from_numpy(img).cuda(), 16, 8).cpu().numpy()
+    assert out.shape == (148, 208, 3) and np.array_equal(out, be.restore(img, tile=16, tile_overlap=8))
+
+
 def test_batch_and_errors():
     cfg = reduced_swinir_config()
     be = backend(cfg, 1)
