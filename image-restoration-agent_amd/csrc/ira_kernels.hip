@@ -886,12 +886,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     const int KT = K >> 4;
     const f16* wbase = W + lane * 8;                 // fragment-major [2][9][NBtot][KT][64][8]
     const long lo_off = 9L * NBtot * KT * 512;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-        const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
-        const f16* wt = wbase + (long)tap * NBtot * KT * 512;
-        for (int s = 0; s < KT; ++s) {
+    for (int s = 0; s < KT; ++s) {                   // k-step outermost, taps innermost: see k_conv3x3_lds
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
+            const f16* wt = wbase + (long)tap * NBtot * KT * 512;
             f32x4 lo4 = *(const f32x4*)(src + 16 * s), hi4 = *(const f32x4*)(src + 16 * s + 4);
             if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
             const half8 b = cvt8(lo4, hi4);
@@ -980,8 +980,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
     const int nsteps = 9 * KT;
     const long lo_off = 9L * NBtot * KT * 512;
     // fragment f of step (tap, s): f < NBW -> hi plane, row block nb0+f; else lo plane, row block nb0+f-NBW
+    // step order: k-step outermost, the 9 taps innermost.  With taps outermost every tap walked all K input channels of
+    // its shifted pixel before the next tap touched the neighbouring pixel's lines again: 9 passes over rows of 32 px x K
+    // fp32 (128 KB per wave at K = 256) that neither L1 nor, for wide images, L2 could hold (PMC: 4.9 GB read per launch for
+    // a 0.54 GB input on the SwinIR 256 -> 64 conv).  Taps innermost touch 3 rows x 34 px x 64 B per k-step.
     auto gsrc = [&](int step, int f) -> const half8* {
-        const int tap = step / KT, s = step - tap * KT;
+        const int s = step / 9, tap = step - 9 * s;
         int nb = nb0 + (f < NBW ? f : f - NBW);
         if (nb >= NBtot) nb = NBtot - 1;                      // partial last chunk: staged but never used
         return (const half8*)(W + (f < NBW ? 0 : lo_off) + (((long)tap * NBtot + nb) * KT + s) * 512 + lane * 8);
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
-        const int tap = step / KT, s = step - tap * KT;
+        const int s = step / 9, tap = step - 9 * s;
         if (step + 1 < nsteps) {
 #pragma unroll
             for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(step + 1, wave + 4 * i);
