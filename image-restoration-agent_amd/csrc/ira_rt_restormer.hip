@@ -1,0 +1,231 @@
+// Restormer (restormer_arch.py:193-284): weight binding, workspace, forward schedule of libira_hip.so's runtime.
+#include "ira_model.h"
+
+namespace ira_rt {
+
+struct Geo {   // per-level geometry for a batch of T tiles of H x W
+    int H[4], W[4], C[4], heads[4], hid[4], Hp[4];
+    long P[4];
+};
+
+static Geo make_geo(const ira_restormer_config& c, int H, int W) {
+    Geo g;
+    for (int l = 0; l < 4; ++l) {
+        g.H[l] = H >> l; g.W[l] = W >> l; g.P[l] = (long)g.H[l] * g.W[l];
+        g.C[l] = c.dim << l; g.heads[l] = c.heads[l]; g.hid[l] = c.hidden[l]; g.Hp[l] = up32(c.hidden[l]);
+    }
+    return g;
+}
+
+static int gram_splits(int T, int heads, long nblk) {
+    // depends on the tile geometry only (never on T): a tile's result must not depend on what else is
+    // in its launch-batch, and the partials are reduced in fixed order (bitwise reproducible)
+    (void)T; (void)heads;
+    const long nsteps = (nblk + 3) / 4;
+    return (int)std::max(1L, std::min(nsteps / 64, 64L));
+}
+
+static bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, Blk& b) {
+    const size_t NBq = up32(3 * C), NBc = up32(C);
+    const bool cb = m->cfg.conv_bias != 0, lb = m->cfg.ln_with_bias != 0;
+    m->err.clear();
+    b.qkv_w = wptr(m, p + ".qkv_w", true, 2 * NBq * C * 2);        // hi + lo planes
+    b.qkv_b = (const float*)wptr(m, p + ".qkv_b", cb || lb, NBq * 4);
+    b.dw1_w = (const float*)wptr(m, p + ".dw1_w", true, (size_t)9 * 3 * C * 4);
+    b.dw1_b = (const float*)wptr(m, p + ".dw1_b", cb, (size_t)3 * C * 4);
+    b.temp = (const float*)wptr(m, p + ".temp", true, (size_t)heads * 4);
+    b.wo = (const float*)wptr(m, p + ".wo", true, (size_t)C * C * 4);
+    b.wo_b = (const float*)wptr(m, p + ".wo_b", cb, NBc * 4);
+    b.pin_w = wptr(m, p + ".pin_w", true, (size_t)2 * 2 * Hp * C * 2);
+    b.pin_b = (const float*)wptr(m, p + ".pin_b", cb || lb, (size_t)2 * Hp * 4);
+    b.dw2_w = (const float*)wptr(m, p + ".dw2_w", true, (size_t)9 * 2 * Hp * 4);
+    b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
+    b.pout_w = wptr(m, p + ".pout_w", true, 2 * NBc * Hp * 2);
+    b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
+    return m->err.empty();
+}
+
+static bool load_stage(ira_model* m, const char* name, int n, int C, int heads, int Hp, std::vector<Blk>& out) {
+    out.resize(n);
+    for (int i = 0; i < n; ++i)
+        if (!load_block(m, std::string(name) + "." + std::to_string(i), C, heads, Hp, out[i])) return false;
+    return true;
+}
+
+bool restormer_bind_weights(ira_model* m) {
+    const ira_restormer_config& c = m->cfg;
+    const Geo g = make_geo(c, 8, 8);
+    const bool cb = c.conv_bias != 0;
+    m->err.clear();
+    m->embed_w = (const float*)wptr(m, "embed_w", true, (size_t)c.dim * c.inp_channels * 9 * 4);
+    if (!m->embed_w) return false;
+    if (!load_stage(m, "encoder_level1", c.num_blocks[0], g.C[0], g.heads[0], g.Hp[0], m->enc1)) return false;
+    if (!load_stage(m, "encoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->enc2)) return false;
+    if (!load_stage(m, "encoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->enc3)) return false;
+    if (!load_stage(m, "latent", c.num_blocks[3], g.C[3], g.heads[3], g.Hp[3], m->lat)) return false;
+    if (!load_stage(m, "decoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->dec3)) return false;
+    if (!load_stage(m, "decoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->dec2)) return false;
+    // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
+    if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], m->dec1)) return false;
+    if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], m->refine)) return false;
+    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
+    m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
+    m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
+    m->down34 = c3("down3_4_w", g.C[2], g.C[2] / 2);
+    m->up43 = c3("up4_3_w", g.C[3], g.C[3] * 2);
+    m->up32 = c3("up3_2_w", g.C[2], g.C[2] * 2);
+    m->up21 = c3("up2_1_w", g.C[1], g.C[1] * 2);
+    m->red3 = wptr(m, "reduce3_w", true, (size_t)2 * up32(g.C[2]) * g.C[3] * 2);
+    m->red2 = wptr(m, "reduce2_w", true, (size_t)2 * up32(g.C[1]) * g.C[2] * 2);
+    m->red3_b = (const float*)wptr(m, "reduce3_b", cb, (size_t)up32(g.C[2]) * 4);
+    m->red2_b = (const float*)wptr(m, "reduce2_b", cb, (size_t)up32(g.C[1]) * 4);
+    m->out_w = c3("output_w", g.C[1], c.out_channels);
+    m->out_b = (const float*)wptr(m, "output_b", cb, (size_t)up32(c.out_channels) * 4);
+    m->embed_b = nullptr;   // OverlapPatchEmbed is always bias=False (restormer_arch.py:157)
+    return m->down12 && m->down23 && m->down34 && m->up43 && m->up32 && m->up21 && m->red3 && m->red2 && m->out_w &&
+           (!cb || (m->red3_b && m->red2_b && m->out_b));
+}
+
+// ---- workspace
+static int ensure_workspace(ira_model* m, int T, int H, int W) {
+    if (m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W) return IRA_OK;
+    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
+    const Geo g = make_geo(m->cfg, H, W);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    const size_t t = (size_t)T;
+    size_t o_xe1 = take(t * g.P[0] * g.C[0] * 4), o_xe2 = take(t * g.P[1] * g.C[1] * 4), o_xe3 = take(t * g.P[2] * g.C[2] * 4),
+           o_x4 = take(t * g.P[3] * g.C[3] * 4), o_xd3 = take(t * g.P[2] * g.C[2] * 4), o_xd2 = take(t * g.P[1] * g.C[1] * 4),
+           o_xd1 = take(t * g.P[0] * g.C[1] * 4), o_u3 = take(t * g.P[2] * g.C[2] * 4), o_u2 = take(t * g.P[1] * g.C[1] * 4),
+           o_u1 = take(t * g.P[0] * g.C[0] * 4);
+    size_t o_ae1 = take(t * g.P[0] * g.C[0] * 4), o_ad1 = take(t * g.P[0] * g.C[1] * 4), o_ae2 = take(t * g.P[1] * g.C[1] * 4),
+           o_ad2 = take(t * g.P[1] * g.C[1] * 4);
+    // branch scratch: max over the (level, channel) pairs actually run; level-1 decoder runs at 2*dim
+    size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0, mattn = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int nvar = (l == 0) ? 2 : 1;
+        for (int var = 0; var < nvar; ++var) {
+            const int C = (var == 1) ? g.C[1] : g.C[l];
+            const int heads = g.heads[l];
+            const int Hp = (var == 1) ? g.Hp[1] : g.Hp[l];
+            const long nblk = (long)g.H[l] * ((g.W[l] + 7) / 8);
+            const int S = gram_splits(T, heads, nblk);
+            const int c = C / heads;
+            mq = std::max(mq, t * g.P[l] * 3 * C * 2);
+            mqk = std::max(mqk, t * nblk * 2 * C * 8 * 2);
+            mv = std::max(mv, t * g.P[l] * C * 2);
+            mh = std::max(mh, t * g.P[l] * 2 * Hp * 2);
+            mg = std::max(mg, t * g.P[l] * Hp * 2);
+            mM = std::max(mM, t * 2 * up32(C) * C * 2);
+            mpart = std::max(mpart, t * S * heads * ((size_t)c * c + 2 * c) * 4);
+            mattn = std::max(mattn, t * (size_t)C * c * 4);
+        }
+    }
+    size_t o_q = take(mq), o_qk = take(mqk), o_v = take(mv), o_h = take(mh), o_g = take(mg), o_M = take(mM), o_p = take(mpart), o_a = take(mattn);
+    hipError_t e = hipMalloc((void**)&m->ws, off);
+    if (e != hipSuccess) {
+        m->ws = nullptr; m->ws_T = 0;
+        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, H, W, hipGetErrorString(e));
+    }
+    m->ws_bytes = off; m->ws_T = T; m->ws_H = H; m->ws_W = W;
+    char* b = m->ws;
+    m->xe1 = (float*)(b + o_xe1); m->xe2 = (float*)(b + o_xe2); m->xe3 = (float*)(b + o_xe3); m->x4 = (float*)(b + o_x4);
+    m->xd3 = (float*)(b + o_xd3); m->xd2 = (float*)(b + o_xd2); m->xd1 = (float*)(b + o_xd1);
+    m->u3 = (float*)(b + o_u3); m->u2 = (float*)(b + o_u2); m->u1 = (float*)(b + o_u1);
+    m->ae1 = (float*)(b + o_ae1); m->ad1 = (float*)(b + o_ad1); m->ae2 = (float*)(b + o_ae2); m->ad2 = (float*)(b + o_ad2);
+    m->qkvp = b + o_q; m->qk = b + o_qk; m->v = b + o_v; m->hp = b + o_h; m->g = b + o_g; m->M = b + o_M;
+    m->part = (float*)(b + o_p); m->attnA = (float*)(b + o_a);
+    // M rows >= C are MFMA padding and must read as zero
+    HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));
+    return IRA_OK;
+}
+
+// ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
+// x: current residual stream buffer; alt: a second buffer of the same size (or nullptr).  The fused FFN writes
+// x -> alt and the two are swapped, so on return x still names the buffer holding the block's output.
+static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp) {
+    const int P = H * W;
+    char k_[8][64];
+    if (m->profile) {
+        const char* fam[8] = {"ln_qkv_1x1", "dwconv_qkv", "gram", "attn_mix", "attn_apply_res", "ln_pin_1x1", "dwconv_gate", "pout_res"};
+        for (int i = 0; i < 8; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
+    } else {
+        for (int i = 0; i < 8; ++i) k_[i][0] = 0;
+    }
+    const int ln = m->cfg.ln_with_bias ? 2 : 1;
+    const int NBq = up32(3 * C) / 32, NBc = up32(C) / 32;
+    const long nblk = (long)H * ((W + 7) / 8);
+    const int S = gram_splits(T, heads, nblk);
+    hipStream_t st = m->st;
+    // MDTA (:111-132)
+    if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
+        char kq[64];
+        if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
+        RUN(m, kq, ira::launch_qkv_fused(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
+    } else {
+        RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
+        RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
+    }
+    RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
+    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
+    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
+    // GDFN (:88-93)
+    if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
+        char kf[64];
+        if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
+        RUN(m, kf, ira::launch_ffn_fused(st, x, alt, ln, C, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, T, H, W, Hp));
+        std::swap(x, alt);
+        return IRA_OK;
+    }
+    RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
+    RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
+    RUN(m, k_[7], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
+    return IRA_OK;
+}
+
+static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp) {
+    for (const Blk& b : blks) {
+        int rc = run_block(m, b, x, alt, T, H, W, C, heads, Hp);
+        if (rc != IRA_OK) return rc;
+    }
+    return IRA_OK;
+}
+
+// ---- Restormer.forward (restormer_arch.py:245-284) on device NHWC fp32, T tiles of H x W (enqueue only)
+int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    const ira_restormer_config& c = m->cfg;
+    if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
+        return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);
+    int rc = ensure_workspace(m, T, H, W);
+    if (rc != IRA_OK) return rc;
+    const Geo g = make_geo(c, H, W);
+    hipStream_t st = m->st;
+    auto nb = [](int N) { return up32(N) / 32; };
+
+    float *e1 = m->xe1, *e2 = m->xe2, *e3 = m->xe3, *l4 = m->x4, *d3 = m->xd3, *d2 = m->xd2, *d1 = m->xd1;
+    RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, e1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
+    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                         // :248
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
+    if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e2, m->down23, nullptr, nullptr, e3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
+    if ((rc = run_stage(m, m->enc3, e3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e3, m->down34, nullptr, nullptr, l4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
+    if ((rc = run_stage(m, m->lat, l4, nullptr, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                         // :257
+
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, l4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], e3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, d3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
+    if ((rc = run_stage(m, m->dec3, d3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
+    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], e2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, d2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
+    if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
+    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], e1, g.C[0], d1, (long)T * g.P[0]));                                        // :270
+    float* a1 = m->ad1;
+    if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
+    a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
+    if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
+    RUN(m, "conv3x3_out", ira::launch_conv3x3(st, d1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
+    return IRA_OK;
+}
+
+}  // namespace ira_rt

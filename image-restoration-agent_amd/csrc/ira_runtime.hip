@@ -1,318 +1,13 @@
-// libira_hip.so runtime: model handle, weight blob, workspace, Restormer forward schedule, tiler,
-// and the C ABI of include/ira.h.  No torch, no CPU compute fallback.
+// libira_hip.so runtime: model life cycle, weight blob, the harnesses (overlap-average tiler, pad-crop tiler) and the C ABI
+// of include/ira.h.  The per-architecture forward schedules live in ira_rt_*.hip.  No torch, no CPU compute fallback.
 //
-// Reference path this replaces: restormer_arch.py:245-284 (network), demo.py:109-168 /
-// model_serving.py:158-209 (harness).  See DESIGN.md for layouts.
-#include "../../include/ira.h"
-#include "ira_kernels.h"
+// Reference paths this replaces: demo.py:109-168 / model_serving.py:158-209 (Restormer harness), SwinIR/inference.py:67-90,294-322,
+// xrestormer_model.py:53-136 (pad-crop tiler).  See DESIGN.md for layouts.
+#include "ira_model.h"
 
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
+namespace ira_rt {
 
-namespace {
-
-thread_local std::string g_err;   // errors of calls that have no handle
-
-struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device pointers into the weight blob
-    const void* qkv_w = nullptr;  const float* qkv_b = nullptr;
-    const float* dw1_w = nullptr; const float* dw1_b = nullptr;
-    const float* temp = nullptr;  const float* wo = nullptr; const float* wo_b = nullptr;
-    const void* pin_w = nullptr;  const float* pin_b = nullptr;
-    const float* dw2_w = nullptr; const float* dw2_b = nullptr;
-    const void* pout_w = nullptr; const float* pout_b = nullptr;
-};
-
-struct Prof { long launches = 0; double ms = 0; };
-
-struct SBlk {  // one SwinTransformerBlock (network_swinir.py:164-279)
-    const void* qkv_w = nullptr; const float* qkv_b = nullptr; const float* bias_tab = nullptr;
-    const void* proj_w = nullptr; const float* proj_b = nullptr;
-    const void* fc1_w = nullptr; const float* fc1_b = nullptr;
-    const void* fc2_w = nullptr; const float* fc2_b = nullptr;
-};
-struct SConv {  // '1conv' (w0 only) or '3conv' (3x3, 1x1, 3x3) residual connection conv (:462-469, :727-735)
-    const void *w0 = nullptr, *w2 = nullptr, *w4 = nullptr;
-    const float *b0 = nullptr, *b2 = nullptr, *b4 = nullptr;
-};
-
-struct NBlk {  // one NAFBlock (NAFNet_arch.py:163-219), device pointers into the weight blob
-    const void* c1_w = nullptr;  const float* c1_b = nullptr;     // conv1 with norm1 folded in
-    const float* dw_w = nullptr; const float* dw_b = nullptr;     // conv2 (depthwise 3x3)
-    const float* sca_w = nullptr; const float* sca_b = nullptr;   // sca.1
-    const void* c3_w = nullptr; const float* c3_b = nullptr;    // diag(beta) conv3, beta*b3 (the SCA scale is applied to its input)
-    const void* c4_w = nullptr;  const float* c4_b = nullptr;     // conv4 with norm2 folded in
-    const void* c5_w = nullptr;  const float* c5_b = nullptr;     // diag(gamma) conv5, gamma*b5
-};
-
-}  // namespace
-
-struct ira_model {
-    int device = -1;
-    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR
-    ira_restormer_config cfg{};
-    ira_nafnet_config ncfg{};
-    ira_dncnn_config dcfg{};
-    ira_swinir_config scfg{};
-    std::vector<std::vector<SBlk>> sw_blocks;
-    std::vector<SConv> sw_lconv;
-    SConv sw_cab;
-    const float *sw_first_w = nullptr, *sw_first_b = nullptr, *sw_pe_g = nullptr, *sw_pe_b = nullptr, *sw_norm_g = nullptr, *sw_norm_b = nullptr;
-    const void *sw_cbu_w = nullptr, *sw_up_w[2] = {nullptr, nullptr}, *sw_hr_w = nullptr, *sw_last_w = nullptr;
-    const float *sw_cbu_b = nullptr, *sw_up_b[2] = {nullptr, nullptr}, *sw_hr_b = nullptr, *sw_last_b = nullptr;
-    float *sw_xp = nullptr, *sw_xf = nullptr, *sw_xa = nullptr, *sw_xb = nullptr, *sw_c1 = nullptr, *sw_c2 = nullptr, *sw_ua = nullptr, *sw_ub = nullptr,
-          *sw_y = nullptr;
-    void *sw_qkv = nullptr, *sw_att = nullptr, *sw_hid = nullptr;
-    const float *dn_first_w = nullptr, *dn_first_b = nullptr, *dn_last_b = nullptr;
-    const void* dn_last_w = nullptr;
-    std::vector<const void*> dn_mid_w;
-    std::vector<const float*> dn_mid_b;
-    // NAFNet weights / workspace
-    std::vector<std::vector<NBlk>> nenc, ndec;
-    std::vector<NBlk> nmid;
-    const float *intro_w = nullptr, *intro_b = nullptr, *ending_b = nullptr;
-    const void* ending_w = nullptr;
-    std::vector<const void*> ndown_w, nup_w;
-    std::vector<const float*> ndown_b;
-    std::vector<float*> nx;          // residual stream per level (encoder output = skip, reused by the decoder)
-    float *npad_in = nullptr, *npad_out = nullptr, *nsca = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
-    std::mutex mu;
-    std::string err, prof_json;
-    bool profile = false;
-    std::map<std::string, Prof> prof;
-
-    // weights
-    char* wblob = nullptr; size_t wbytes = 0;
-    std::map<std::string, std::pair<size_t, size_t>> toc;   // name -> (offset, nbytes)
-    std::vector<Blk> enc1, enc2, enc3, lat, dec3, dec2, dec1, refine;
-    const float* embed_w = nullptr; const float* embed_b = nullptr;
-    const void *down12 = nullptr, *down23 = nullptr, *down34 = nullptr, *up43 = nullptr, *up32 = nullptr, *up21 = nullptr;
-    const void *red3 = nullptr, *red2 = nullptr; const float *red3_b = nullptr, *red2_b = nullptr;
-    const void* out_w = nullptr; const float* out_b = nullptr;
-
-    // workspace
-    char* ws = nullptr; size_t ws_bytes = 0;
-    int ws_T = 0, ws_H = 0, ws_W = 0;
-    float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
-    float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
-    bool use_fused_ffn = true;
-    void *qkvp, *qk, *v, *hp, *g, *M;
-    int max_batch = 0;
-    // harness scratch
-    char* hs = nullptr; size_t hs_bytes = 0;
-
-    int fail(int code, const char* fmt, ...) {
-        char buf[512];
-        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-        err = buf;
-        return code;
-    }
-};
-
-namespace {
-
-int gfail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIP_TRY(m, expr)                                                                          \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return (m)->fail(e_ == hipErrorOutOfMemory ? IRA_ERR_OOM : IRA_ERR_HIP, "%s: %s (%s:%d)", #expr, \
-                             hipGetErrorString(e_), __FILE__, __LINE__);                          \
-    } while (0)
-
-inline int up32(int n) { return (n + 31) / 32 * 32; }
-inline size_t al256(size_t n) { return (n + 255) / 256 * 256; }
-
-struct Geo {   // per-level geometry for a batch of T tiles of H x W
-    int H[4], W[4], C[4], heads[4], hid[4], Hp[4];
-    long P[4];
-};
-
-Geo make_geo(const ira_restormer_config& c, int H, int W) {
-    Geo g;
-    for (int l = 0; l < 4; ++l) {
-        g.H[l] = H >> l; g.W[l] = W >> l; g.P[l] = (long)g.H[l] * g.W[l];
-        g.C[l] = c.dim << l; g.heads[l] = c.heads[l]; g.hid[l] = c.hidden[l]; g.Hp[l] = up32(c.hidden[l]);
-    }
-    return g;
-}
-
-int gram_splits(int T, int heads, long nblk) {
-    // depends on the tile geometry only (never on T): a tile's result must not depend on what else is
-    // in its launch-batch, and the partials are reduced in fixed order (bitwise reproducible)
-    (void)T; (void)heads;
-    const long nsteps = (nblk + 3) / 4;
-    return (int)std::max(1L, std::min(nsteps / 64, 64L));
-}
-
-// ---- profiling wrapper: run one launch, optionally bracketed by events
-template <class F>
-int run(ira_model* m, const char* family, F&& f) {
-    if (m->profile) {
-        HIP_TRY(m, hipEventRecord(m->pev0, m->st));
-        HIP_TRY(m, f());
-        HIP_TRY(m, hipEventRecord(m->pev1, m->st));
-        HIP_TRY(m, hipEventSynchronize(m->pev1));
-        float ms = 0;
-        HIP_TRY(m, hipEventElapsedTime(&ms, m->pev0, m->pev1));
-        Prof& p = m->prof[family];
-        p.launches++; p.ms += ms;
-        return IRA_OK;
-    }
-    HIP_TRY(m, f());
-    return IRA_OK;
-}
-#define RUN(m, fam, call)                                        \
-    do {                                                         \
-        int rc_ = run((m), (fam), [&]() { return (call); });     \
-        if (rc_ != IRA_OK) return rc_;                           \
-    } while (0)
-
-// ---- weights
-struct TocEntry { char name[112]; uint64_t offset; uint64_t nbytes; };
-struct BlobHeader { char magic[8]; uint32_t n_entries; uint32_t reserved; };
-
-const void* wptr(ira_model* m, const std::string& name, bool required, size_t expect_bytes = 0) {
-    auto it = m->toc.find(name);
-    if (it == m->toc.end()) {
-        if (required) m->err = "weight blob: missing entry '" + name + "'";
-        return nullptr;
-    }
-    if (expect_bytes && it->second.second != expect_bytes) {
-        m->err = "weight blob: entry '" + name + "' has " + std::to_string(it->second.second) + " bytes, expected " +
-                 std::to_string(expect_bytes);
-        return nullptr;
-    }
-    return m->wblob + it->second.first;
-}
-
-bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, Blk& b) {
-    const size_t NBq = up32(3 * C), NBc = up32(C);
-    const bool cb = m->cfg.conv_bias != 0, lb = m->cfg.ln_with_bias != 0;
-    m->err.clear();
-    b.qkv_w = wptr(m, p + ".qkv_w", true, 2 * NBq * C * 2);        // hi + lo planes
-    b.qkv_b = (const float*)wptr(m, p + ".qkv_b", cb || lb, NBq * 4);
-    b.dw1_w = (const float*)wptr(m, p + ".dw1_w", true, (size_t)9 * 3 * C * 4);
-    b.dw1_b = (const float*)wptr(m, p + ".dw1_b", cb, (size_t)3 * C * 4);
-    b.temp = (const float*)wptr(m, p + ".temp", true, (size_t)heads * 4);
-    b.wo = (const float*)wptr(m, p + ".wo", true, (size_t)C * C * 4);
-    b.wo_b = (const float*)wptr(m, p + ".wo_b", cb, NBc * 4);
-    b.pin_w = wptr(m, p + ".pin_w", true, (size_t)2 * 2 * Hp * C * 2);
-    b.pin_b = (const float*)wptr(m, p + ".pin_b", cb || lb, (size_t)2 * Hp * 4);
-    b.dw2_w = (const float*)wptr(m, p + ".dw2_w", true, (size_t)9 * 2 * Hp * 4);
-    b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
-    b.pout_w = wptr(m, p + ".pout_w", true, 2 * NBc * Hp * 2);
-    b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
-    return m->err.empty();
-}
-
-bool load_stage(ira_model* m, const char* name, int n, int C, int heads, int Hp, std::vector<Blk>& out) {
-    out.resize(n);
-    for (int i = 0; i < n; ++i)
-        if (!load_block(m, std::string(name) + "." + std::to_string(i), C, heads, Hp, out[i])) return false;
-    return true;
-}
-
-bool bind_weights(ira_model* m) {
-    const ira_restormer_config& c = m->cfg;
-    const Geo g = make_geo(c, 8, 8);
-    const bool cb = c.conv_bias != 0;
-    m->err.clear();
-    m->embed_w = (const float*)wptr(m, "embed_w", true, (size_t)c.dim * c.inp_channels * 9 * 4);
-    if (!m->embed_w) return false;
-    if (!load_stage(m, "encoder_level1", c.num_blocks[0], g.C[0], g.heads[0], g.Hp[0], m->enc1)) return false;
-    if (!load_stage(m, "encoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->enc2)) return false;
-    if (!load_stage(m, "encoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->enc3)) return false;
-    if (!load_stage(m, "latent", c.num_blocks[3], g.C[3], g.heads[3], g.Hp[3], m->lat)) return false;
-    if (!load_stage(m, "decoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->dec3)) return false;
-    if (!load_stage(m, "decoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->dec2)) return false;
-    // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
-    if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], m->dec1)) return false;
-    if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], m->refine)) return false;
-    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
-    m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
-    m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
-    m->down34 = c3("down3_4_w", g.C[2], g.C[2] / 2);
-    m->up43 = c3("up4_3_w", g.C[3], g.C[3] * 2);
-    m->up32 = c3("up3_2_w", g.C[2], g.C[2] * 2);
-    m->up21 = c3("up2_1_w", g.C[1], g.C[1] * 2);
-    m->red3 = wptr(m, "reduce3_w", true, (size_t)2 * up32(g.C[2]) * g.C[3] * 2);
-    m->red2 = wptr(m, "reduce2_w", true, (size_t)2 * up32(g.C[1]) * g.C[2] * 2);
-    m->red3_b = (const float*)wptr(m, "reduce3_b", cb, (size_t)up32(g.C[2]) * 4);
-    m->red2_b = (const float*)wptr(m, "reduce2_b", cb, (size_t)up32(g.C[1]) * 4);
-    m->out_w = c3("output_w", g.C[1], c.out_channels);
-    m->out_b = (const float*)wptr(m, "output_b", cb, (size_t)up32(c.out_channels) * 4);
-    m->embed_b = nullptr;   // OverlapPatchEmbed is always bias=False (restormer_arch.py:157)
-    return m->down12 && m->down23 && m->down34 && m->up43 && m->up32 && m->up21 && m->red3 && m->red2 && m->out_w &&
-           (!cb || (m->red3_b && m->red2_b && m->out_b));
-}
-
-// ---- workspace
-int ensure_workspace(ira_model* m, int T, int H, int W) {
-    if (m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W) return IRA_OK;
-    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
-    const Geo g = make_geo(m->cfg, H, W);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
-    const size_t t = (size_t)T;
-    size_t o_xe1 = take(t * g.P[0] * g.C[0] * 4), o_xe2 = take(t * g.P[1] * g.C[1] * 4), o_xe3 = take(t * g.P[2] * g.C[2] * 4),
-           o_x4 = take(t * g.P[3] * g.C[3] * 4), o_xd3 = take(t * g.P[2] * g.C[2] * 4), o_xd2 = take(t * g.P[1] * g.C[1] * 4),
-           o_xd1 = take(t * g.P[0] * g.C[1] * 4), o_u3 = take(t * g.P[2] * g.C[2] * 4), o_u2 = take(t * g.P[1] * g.C[1] * 4),
-           o_u1 = take(t * g.P[0] * g.C[0] * 4);
-    size_t o_ae1 = take(t * g.P[0] * g.C[0] * 4), o_ad1 = take(t * g.P[0] * g.C[1] * 4), o_ae2 = take(t * g.P[1] * g.C[1] * 4),
-           o_ad2 = take(t * g.P[1] * g.C[1] * 4);
-    // branch scratch: max over the (level, channel) pairs actually run; level-1 decoder runs at 2*dim
-    size_t mq = 0, mqk = 0, mv = 0, mh = 0, mg = 0, mM = 0, mpart = 0, mattn = 0;
-    for (int l = 0; l < 4; ++l) {
-        const int nvar = (l == 0) ? 2 : 1;
-        for (int var = 0; var < nvar; ++var) {
-            const int C = (var == 1) ? g.C[1] : g.C[l];
-            const int heads = g.heads[l];
-            const int Hp = (var == 1) ? g.Hp[1] : g.Hp[l];
-            const long nblk = (long)g.H[l] * ((g.W[l] + 7) / 8);
-            const int S = gram_splits(T, heads, nblk);
-            const int c = C / heads;
-            mq = std::max(mq, t * g.P[l] * 3 * C * 2);
-            mqk = std::max(mqk, t * nblk * 2 * C * 8 * 2);
-            mv = std::max(mv, t * g.P[l] * C * 2);
-            mh = std::max(mh, t * g.P[l] * 2 * Hp * 2);
-            mg = std::max(mg, t * g.P[l] * Hp * 2);
-            mM = std::max(mM, t * 2 * up32(C) * C * 2);
-            mpart = std::max(mpart, t * S * heads * ((size_t)c * c + 2 * c) * 4);
-            mattn = std::max(mattn, t * (size_t)C * c * 4);
-        }
-    }
-    size_t o_q = take(mq), o_qk = take(mqk), o_v = take(mv), o_h = take(mh), o_g = take(mg), o_M = take(mM), o_p = take(mpart), o_a = take(mattn);
-    hipError_t e = hipMalloc((void**)&m->ws, off);
-    if (e != hipSuccess) {
-        m->ws = nullptr; m->ws_T = 0;
-        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, H, W, hipGetErrorString(e));
-    }
-    m->ws_bytes = off; m->ws_T = T; m->ws_H = H; m->ws_W = W;
-    char* b = m->ws;
-    m->xe1 = (float*)(b + o_xe1); m->xe2 = (float*)(b + o_xe2); m->xe3 = (float*)(b + o_xe3); m->x4 = (float*)(b + o_x4);
-    m->xd3 = (float*)(b + o_xd3); m->xd2 = (float*)(b + o_xd2); m->xd1 = (float*)(b + o_xd1);
-    m->u3 = (float*)(b + o_u3); m->u2 = (float*)(b + o_u2); m->u1 = (float*)(b + o_u1);
-    m->ae1 = (float*)(b + o_ae1); m->ad1 = (float*)(b + o_ad1); m->ae2 = (float*)(b + o_ae2); m->ad2 = (float*)(b + o_ad2);
-    m->qkvp = b + o_q; m->qk = b + o_qk; m->v = b + o_v; m->hp = b + o_h; m->g = b + o_g; m->M = b + o_M;
-    m->part = (float*)(b + o_p); m->attnA = (float*)(b + o_a);
-    // M rows >= C are MFMA padding and must read as zero
-    HIP_TRY(m, hipMemsetAsync(m->M, 0, al256(mM), m->st));
-    return IRA_OK;
-}
+thread_local std::string g_err;
 
 int ensure_scratch(ira_model* m, size_t bytes) {
     if (m->hs && bytes <= m->hs_bytes) return IRA_OK;
@@ -323,495 +18,11 @@ int ensure_scratch(ira_model* m, size_t bytes) {
     return IRA_OK;
 }
 
-// ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
-// x: current residual stream buffer; alt: a second buffer of the same size (or nullptr).  The fused FFN writes
-// x -> alt and the two are swapped, so on return x still names the buffer holding the block's output.
-int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp) {
-    const int P = H * W;
-    char k_[8][64];
-    if (m->profile) {
-        const char* fam[8] = {"ln_qkv_1x1", "dwconv_qkv", "gram", "attn_mix", "attn_apply_res", "ln_pin_1x1", "dwconv_gate", "pout_res"};
-        for (int i = 0; i < 8; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
-    } else {
-        for (int i = 0; i < 8; ++i) k_[i][0] = 0;
-    }
-    const int ln = m->cfg.ln_with_bias ? 2 : 1;
-    const int NBq = up32(3 * C) / 32, NBc = up32(C) / 32;
-    const long nblk = (long)H * ((W + 7) / 8);
-    const int S = gram_splits(T, heads, nblk);
-    hipStream_t st = m->st;
-    // MDTA (:111-132)
-    if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
-        char kq[64];
-        if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
-        RUN(m, kq, ira::launch_qkv_fused(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
-    } else {
-        RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
-        RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
-    }
-    RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
-    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
-    // GDFN (:88-93)
-    if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
-        char kf[64];
-        if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
-        RUN(m, kf, ira::launch_ffn_fused(st, x, alt, ln, C, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, T, H, W, Hp));
-        std::swap(x, alt);
-        return IRA_OK;
-    }
-    RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
-    RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
-    RUN(m, k_[7], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
-    return IRA_OK;
-}
+}  // namespace ira_rt
 
-int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp) {
-    for (const Blk& b : blks) {
-        int rc = run_block(m, b, x, alt, T, H, W, C, heads, Hp);
-        if (rc != IRA_OK) return rc;
-    }
-    return IRA_OK;
-}
+using namespace ira_rt;
 
-// ---- Restormer.forward (restormer_arch.py:245-284) on device NHWC fp32, T tiles of H x W (enqueue only)
-int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
-    const ira_restormer_config& c = m->cfg;
-    if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
-        return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);
-    int rc = ensure_workspace(m, T, H, W);
-    if (rc != IRA_OK) return rc;
-    const Geo g = make_geo(c, H, W);
-    hipStream_t st = m->st;
-    auto nb = [](int N) { return up32(N) / 32; };
-
-    float *e1 = m->xe1, *e2 = m->xe2, *e3 = m->xe3, *l4 = m->x4, *d3 = m->xd3, *d2 = m->xd2, *d1 = m->xd1;
-    RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, e1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
-    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                         // :248
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
-    if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e2, m->down23, nullptr, nullptr, e3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
-    if ((rc = run_stage(m, m->enc3, e3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e3, m->down34, nullptr, nullptr, l4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
-    if ((rc = run_stage(m, m->lat, l4, nullptr, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                         // :257
-
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, l4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
-    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], e3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, d3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
-    if ((rc = run_stage(m, m->dec3, d3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
-    RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], e2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, d2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
-    if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
-    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], e1, g.C[0], d1, (long)T * g.P[0]));                                        // :270
-    float* a1 = m->ad1;
-    if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
-    a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
-    if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
-    RUN(m, "conv3x3_out", ira::launch_conv3x3(st, d1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
-    return IRA_OK;
-}
-
-
-// =============================================================================================
-// NAFNet (NAFNet_arch.py:249-361): weights, workspace, forward schedule
-int naf_levels(const ira_nafnet_config& c) { return c.n_levels; }
-
-bool naf_load_block(ira_model* m, const std::string& p, int c, NBlk& b) {
-    const size_t NBc = up32(c), NB2 = up32(2 * c);
-    m->err.clear();
-    b.c1_w = wptr(m, p + ".c1_w", true, 2 * NB2 * c * 2);
-    b.c1_b = (const float*)wptr(m, p + ".c1_b", true, NB2 * 4);
-    b.dw_w = (const float*)wptr(m, p + ".dw_w", true, (size_t)9 * 2 * c * 4);
-    b.dw_b = (const float*)wptr(m, p + ".dw_b", true, (size_t)2 * c * 4);
-    b.sca_w = (const float*)wptr(m, p + ".sca_w", true, (size_t)c * c * 4);
-    b.sca_b = (const float*)wptr(m, p + ".sca_b", true, (size_t)c * 4);
-    b.c3_w = wptr(m, p + ".c3_w", true, 2 * NBc * c * 2);
-    b.c3_b = (const float*)wptr(m, p + ".c3_b", true, NBc * 4);
-    b.c4_w = wptr(m, p + ".c4_w", true, 2 * NB2 * c * 2);
-    b.c4_b = (const float*)wptr(m, p + ".c4_b", true, NB2 * 4);
-    b.c5_w = wptr(m, p + ".c5_w", true, 2 * NBc * c * 2);
-    b.c5_b = (const float*)wptr(m, p + ".c5_b", true, NBc * 4);
-    return m->err.empty();
-}
-
-bool naf_bind_weights(ira_model* m) {
-    const ira_nafnet_config& c = m->ncfg;
-    const int L = c.n_levels;
-    m->err.clear();
-    m->intro_w = (const float*)wptr(m, "intro_w", true, (size_t)c.width * c.img_channel * 9 * 4);
-    m->intro_b = (const float*)wptr(m, "intro_b", true, (size_t)c.width * 4);
-    m->ending_w = wptr(m, "ending_w", true, (size_t)2 * 9 * up32(c.img_channel) * c.width * 2);
-    m->ending_b = (const float*)wptr(m, "ending_b", true, (size_t)up32(c.img_channel) * 4);
-    if (!m->intro_w || !m->intro_b || !m->ending_w || !m->ending_b) return false;
-    m->nenc.assign(L, {}); m->ndec.assign(L, {});
-    m->ndown_w.assign(L, nullptr); m->ndown_b.assign(L, nullptr); m->nup_w.assign(L, nullptr);
-    int ch = c.width;
-    for (int i = 0; i < L; ++i) {
-        m->nenc[i].resize(c.enc_blk_nums[i]);
-        for (int k = 0; k < c.enc_blk_nums[i]; ++k)
-            if (!naf_load_block(m, "enc." + std::to_string(i) + "." + std::to_string(k), ch, m->nenc[i][k])) return false;
-        m->ndown_w[i] = wptr(m, "down." + std::to_string(i) + "_w", true, (size_t)2 * up32(2 * ch) * 4 * ch * 2);
-        m->ndown_b[i] = (const float*)wptr(m, "down." + std::to_string(i) + "_b", true, (size_t)up32(2 * ch) * 4);
-        if (!m->ndown_w[i] || !m->ndown_b[i]) return false;
-        ch *= 2;
-    }
-    m->nmid.resize(c.middle_blk_num);
-    for (int k = 0; k < c.middle_blk_num; ++k)
-        if (!naf_load_block(m, "mid." + std::to_string(k), ch, m->nmid[k])) return false;
-    for (int i = 0; i < L; ++i) {
-        m->nup_w[i] = wptr(m, "up." + std::to_string(i) + "_w", true, (size_t)2 * up32(2 * ch) * ch * 2);
-        if (!m->nup_w[i]) return false;
-        ch /= 2;
-        m->ndec[i].resize(c.dec_blk_nums[i]);
-        for (int k = 0; k < c.dec_blk_nums[i]; ++k)
-            if (!naf_load_block(m, "dec." + std::to_string(i) + "." + std::to_string(k), ch, m->ndec[i][k])) return false;
-    }
-    return true;
-}
-
-// (H, W): padded size, multiples of 2^L
-int naf_ensure_workspace(ira_model* m, int T, int H, int W) {
-    if (m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W) return IRA_OK;
-    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
-    const ira_nafnet_config& c = m->ncfg;
-    const int L = c.n_levels;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
-    const size_t t = (size_t)T;
-    std::vector<size_t> o_x(L + 1);
-    size_t mt1 = 0, mg = 0, mpart = 0, ms = 0;
-    for (int l = 0; l <= L; ++l) {
-        const size_t ch = (size_t)c.width << l, P = (size_t)(H >> l) * (W >> l);
-        o_x[l] = take(t * P * ch * 4);
-        mt1 = std::max(mt1, t * P * 2 * ch * 2);
-        mg = std::max(mg, t * P * ch * 2);
-        mpart = std::max(mpart, t * (size_t)ira::naf_dw_sg_blocks(H >> l, W >> l, (int)ch) * ch * 4);
-        ms = std::max(ms, t * ch * 4);
-    }
-    const size_t o_t1 = take(mt1), o_g = take(mg), o_p = take(mpart), o_s = take(ms);
-    const size_t o_pi = take(t * H * W * c.img_channel * 4), o_po = take(t * H * W * c.img_channel * 4);
-    hipError_t e = hipMalloc((void**)&m->ws, off);
-    if (e != hipSuccess) {
-        m->ws = nullptr; m->ws_T = 0;
-        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, H, W, hipGetErrorString(e));
-    }
-    m->ws_bytes = off; m->ws_T = T; m->ws_H = H; m->ws_W = W;
-    char* b = m->ws;
-    m->nx.resize(L + 1);
-    for (int l = 0; l <= L; ++l) m->nx[l] = (float*)(b + o_x[l]);
-    m->hp = b + o_t1; m->g = b + o_g; m->part = (float*)(b + o_p); m->nsca = (float*)(b + o_s);
-    m->npad_in = (float*)(b + o_pi); m->npad_out = (float*)(b + o_po);
-    return IRA_OK;
-}
-
-// one NAFBlock in place on x (NAFNet_arch.py:198-219)
-int naf_run_block(ira_model* m, const NBlk& b, float* x, int T, int H, int W, int c) {
-    const int P = H * W, NBc = up32(c) / 32, NB2 = up32(2 * c) / 32;
-    char k_[6][64];
-    if (m->profile) {
-        const char* fam[6] = {"naf_ln_conv1", "naf_dw_gate", "naf_sca", "naf_conv3_res", "naf_ln_conv4", "naf_gate_conv5_res"};
-        for (int i = 0; i < 6; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], c, H, W, T);
-    } else {
-        for (int i = 0; i < 6; ++i) k_[i][0] = 0;
-    }
-    hipStream_t st = m->st;
-    const int bpt = ira::naf_dw_sg_blocks(H, W, c);
-    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, c, b.c1_w, b.c1_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
-    RUN(m, k_[1], ira::launch_naf_dw_sg(st, m->hp, b.dw_w, b.dw_b, m->g, m->part, T, H, W, c));
-    RUN(m, k_[2], ira::launch_naf_sca(st, m->part, bpt, (long)P, b.sca_w, b.sca_b, m->nsca, T, c));
-    if (m->use_fused_ffn && ira::naf_tail_supported(c)) {
-        char kt[64];
-        if (m->profile) snprintf(kt, sizeof kt, "naf_tail_fused|C%d|%dx%d|T%d", c, H, W, T); else kt[0] = 0;
-        RUN(m, kt, ira::launch_naf_tail(st, m->g, m->nsca, x, c, b.c3_w, b.c3_b, b.c4_w, b.c4_b, b.c5_w, b.c5_b, T, P));
-        return IRA_OK;
-    }
-    RUN(m, k_[3], ira::launch_naf_pw(st, 4, 0, m->g, c, b.c3_w, 0, b.c3_b, x, x, c, NBc, T, H, W, m->nsca));
-    RUN(m, k_[4], ira::launch_pw_kres(st, x, true, 2, c, b.c4_w, b.c4_b, m->hp, 2 * c, 2 * c, NB2, T, P, 1e-6f));
-    RUN(m, k_[5], ira::launch_naf_pw(st, 1, 0, m->hp, c, b.c5_w, 0, b.c5_b, x, x, c, NBc, T, H, W));
-    return IRA_OK;
-}
-
-// NAFNet.forward (:301-326) on device NHWC fp32 (T, H, W, img_channel), any H, W (zero padded to 2^L here)
-int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
-    const ira_nafnet_config& c = m->ncfg;
-    const int L = c.n_levels, ps = 1 << L;
-    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
-    const int Hp = (H + ps - 1) / ps * ps, Wp = (W + ps - 1) / ps * ps;          // check_image_size :356-361
-    int rc = naf_ensure_workspace(m, T, Hp, Wp);
-    if (rc != IRA_OK) return rc;
-    hipStream_t st = m->st;
-    const bool padded = (Hp != H) || (Wp != W);
-    const float* xin = in;
-    float* xout = out;
-    if (padded) {
-        RUN(m, "naf_pad", ira::launch_naf_pad_crop(st, in, m->npad_in, T, H, W, Hp, Wp, c.img_channel));
-        xin = m->npad_in; xout = m->npad_out;
-    }
-    auto nb = [](int N) { return up32(N) / 32; };
-    RUN(m, "naf_intro3x3", ira::launch_embed(st, xin, m->intro_w, m->intro_b, m->nx[0], T, Hp, Wp, c.img_channel, c.width));   // :305
-    int ch = c.width, h = Hp, w = Wp;
-    for (int l = 0; l < L; ++l) {                                                                   // :309-312
-        for (const NBlk& b : m->nenc[l]) if ((rc = naf_run_block(m, b, m->nx[l], T, h, w, ch))) return rc;
-        RUN(m, "naf_down2x2", ira::launch_naf_pw(st, 2, 0, m->nx[l], 4 * ch, m->ndown_w[l], 0, m->ndown_b[l], nullptr, m->nx[l + 1],
-                                                 2 * ch, nb(2 * ch), T, h / 2, w / 2));
-        ch *= 2; h /= 2; w /= 2;
-    }
-    for (const NBlk& b : m->nmid) if ((rc = naf_run_block(m, b, m->nx[L], T, h, w, ch))) return rc;  // :314
-    for (int i = 0; i < L; ++i) {                                                                   // :316-321
-        const int l = L - 1 - i;
-        // x = PixelShuffle(conv1x1(x)) + enc_skip, written over the skip buffer
-        RUN(m, "naf_up_shuffle_add", ira::launch_naf_pw(st, 3, 1, m->nx[l + 1], ch, m->nup_w[i], 0, nullptr, m->nx[l], m->nx[l],
-                                                        2 * ch, nb(2 * ch), T, h, w));
-        ch /= 2; h *= 2; w *= 2;
-        for (const NBlk& b : m->ndec[i]) if ((rc = naf_run_block(m, b, m->nx[l], T, h, w, ch))) return rc;
-    }
-    RUN(m, "naf_ending3x3", ira::launch_conv3x3(st, m->nx[0], m->ending_w, m->ending_b, xin, xout, 3, T, Hp, Wp, c.width,
-                                                c.img_channel, nb(c.img_channel)));                  // :323-324
-    if (padded) RUN(m, "naf_crop", ira::launch_naf_pad_crop(st, m->npad_out, out, T, Hp, Wp, H, W, c.img_channel));   // :326
-    return IRA_OK;
-}
-
-// =============================================================================================
-// DnCNN (BASELINE config 1; no reference code: a build-defined plumbing model, see ira_amd/dncnn.py):
-// conv3x3(in->nc)+ReLU, (nb-2) x [conv3x3(nc->nc) + BN (folded by the packer) + ReLU], conv3x3(nc->in); out = x - net(x).
-bool dn_bind_weights(ira_model* m) {
-    const ira_dncnn_config& c = m->dcfg;
-    m->err.clear();
-    m->dn_first_w = (const float*)wptr(m, "first_w", true, (size_t)c.nc * c.in_nc * 9 * 4);
-    m->dn_first_b = (const float*)wptr(m, "first_b", true, (size_t)c.nc * 4);
-    m->dn_last_w = wptr(m, "last_w", true, (size_t)2 * 9 * up32(c.in_nc) * c.nc * 2);
-    m->dn_last_b = (const float*)wptr(m, "last_b", true, (size_t)up32(c.in_nc) * 4);
-    if (!m->dn_first_w || !m->dn_first_b || !m->dn_last_w || !m->dn_last_b) return false;
-    m->dn_mid_w.assign(c.nb - 2, nullptr); m->dn_mid_b.assign(c.nb - 2, nullptr);
-    for (int i = 0; i < c.nb - 2; ++i) {
-        m->dn_mid_w[i] = wptr(m, "mid." + std::to_string(i) + "_w", true, (size_t)2 * 9 * up32(c.nc) * c.nc * 2);
-        m->dn_mid_b[i] = (const float*)wptr(m, "mid." + std::to_string(i) + "_b", true, (size_t)up32(c.nc) * 4);
-        if (!m->dn_mid_w[i] || !m->dn_mid_b[i]) return false;
-    }
-    return true;
-}
-
-int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
-    const ira_dncnn_config& c = m->dcfg;
-    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
-    if (!(m->ws && T <= m->ws_T && H == m->ws_H && W == m->ws_W)) {
-        if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
-        const size_t one = al256((size_t)T * H * W * c.nc * 4);
-        hipError_t e = hipMalloc((void**)&m->ws, 2 * one);
-        if (e != hipSuccess) { m->ws = nullptr; m->ws_T = 0; return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu): %s", 2 * one, hipGetErrorString(e)); }
-        m->ws_bytes = 2 * one; m->ws_T = T; m->ws_H = H; m->ws_W = W;
-        m->nx.assign(2, nullptr);
-        m->nx[0] = (float*)m->ws; m->nx[1] = (float*)(m->ws + one);
-    }
-    hipStream_t st = m->st;
-    const int nbc = up32(c.nc) / 32;
-    float *a = m->nx[0], *b = m->nx[1];
-    RUN(m, "dncnn_first3x3_relu", ira::launch_embed(st, in, m->dn_first_w, m->dn_first_b, a, T, H, W, c.in_nc, c.nc, 1));
-    for (int i = 0; i < c.nb - 2; ++i) {
-        RUN(m, "dncnn_conv3x3_bn_relu", ira::launch_conv3x3(st, a, m->dn_mid_w[i], m->dn_mid_b[i], nullptr, b, 4, T, H, W, c.nc, c.nc, nbc));
-        std::swap(a, b);
-    }
-    // weights and bias of the last conv are negated by the packer: out = x + (-(conv)) = x - noise
-    RUN(m, "dncnn_last3x3_residual", ira::launch_conv3x3(st, a, m->dn_last_w, m->dn_last_b, in, out, 3, T, H, W, c.nc, c.in_nc, up32(c.in_nc) / 32));
-    return IRA_OK;
-}
-
-// =============================================================================================
-// SwinIR (network_swinir.py:618-840): weights, workspace, forward schedule
-struct SwGeo { int C, Cp, hid, hidp, qp, heads_max; };
-SwGeo sw_geo(const ira_swinir_config& c) {
-    SwGeo g;
-    g.C = c.embed_dim; g.Cp = up32(c.embed_dim); g.hid = c.mlp_hidden; g.hidp = up32(c.mlp_hidden); g.qp = up32(c.embed_dim / 4);
-    g.heads_max = 0;
-    for (int i = 0; i < c.n_layers; ++i) g.heads_max = std::max(g.heads_max, c.num_heads[i]);
-    return g;
-}
-
-bool sw_load_conv(ira_model* m, const std::string& p, bool three, const SwGeo& g, SConv& c) {
-    if (!three) {
-        c.w0 = wptr(m, p + "_w", true, (size_t)2 * 9 * g.Cp * g.Cp * 2);
-        c.b0 = (const float*)wptr(m, p + "_b", true, (size_t)g.Cp * 4);
-        return c.w0 && c.b0;
-    }
-    c.w0 = wptr(m, p + ".0_w", true, (size_t)2 * 9 * g.qp * g.Cp * 2);
-    c.b0 = (const float*)wptr(m, p + ".0_b", true, (size_t)g.qp * 4);
-    c.w2 = wptr(m, p + ".2_w", true, (size_t)2 * g.qp * g.qp * 2);
-    c.b2 = (const float*)wptr(m, p + ".2_b", true, (size_t)g.qp * 4);
-    c.w4 = wptr(m, p + ".4_w", true, (size_t)2 * 9 * g.Cp * g.qp * 2);
-    c.b4 = (const float*)wptr(m, p + ".4_b", true, (size_t)g.Cp * 4);
-    return c.w0 && c.b0 && c.w2 && c.b2 && c.w4 && c.b4;
-}
-
-bool sw_bind_weights(ira_model* m) {
-    const ira_swinir_config& c = m->scfg;
-    const SwGeo g = sw_geo(c);
-    const bool three = c.resi_3conv != 0;
-    m->err.clear();
-    m->sw_first_w = (const float*)wptr(m, "first_w", true, (size_t)g.Cp * c.in_chans * 9 * 4);
-    m->sw_first_b = (const float*)wptr(m, "first_b", true, (size_t)g.Cp * 4);
-    m->sw_pe_g = (const float*)wptr(m, "pe_norm_g", true, (size_t)g.Cp * 4);
-    m->sw_pe_b = (const float*)wptr(m, "pe_norm_b", true, (size_t)g.Cp * 4);
-    m->sw_norm_g = (const float*)wptr(m, "norm_g", true, (size_t)g.Cp * 4);
-    m->sw_norm_b = (const float*)wptr(m, "norm_b", true, (size_t)g.Cp * 4);
-    if (!m->sw_first_w || !m->sw_first_b || !m->sw_pe_g || !m->sw_pe_b || !m->sw_norm_g || !m->sw_norm_b) return false;
-    m->sw_blocks.assign(c.n_layers, {});
-    m->sw_lconv.assign(c.n_layers, SConv());
-    for (int i = 0; i < c.n_layers; ++i) {
-        const int heads = c.num_heads[i], Kh = heads * 32;
-        m->sw_blocks[i].resize(c.depths[i]);
-        for (int k = 0; k < c.depths[i]; ++k) {
-            const std::string p = "l" + std::to_string(i) + ".b" + std::to_string(k);
-            SBlk& b = m->sw_blocks[i][k];
-            b.qkv_w = wptr(m, p + ".qkv_w", true, (size_t)2 * 3 * Kh * g.Cp * 2);
-            b.qkv_b = (const float*)wptr(m, p + ".qkv_b", true, (size_t)3 * Kh * 4);
-            b.bias_tab = (const float*)wptr(m, p + ".bias_tab", true, (size_t)heads * 64 * 64 * 4);
-            b.proj_w = wptr(m, p + ".proj_w", true, (size_t)2 * g.Cp * Kh * 2);
-            b.proj_b = (const float*)wptr(m, p + ".proj_b", true, (size_t)g.Cp * 4);
-            b.fc1_w = wptr(m, p + ".fc1_w", true, (size_t)2 * g.hidp * g.Cp * 2);
-            b.fc1_b = (const float*)wptr(m, p + ".fc1_b", true, (size_t)g.hidp * 4);
-            b.fc2_w = wptr(m, p + ".fc2_w", true, (size_t)2 * g.Cp * g.hidp * 2);
-            b.fc2_b = (const float*)wptr(m, p + ".fc2_b", true, (size_t)g.Cp * 4);
-            if (!b.qkv_w || !b.qkv_b || !b.bias_tab || !b.proj_w || !b.proj_b || !b.fc1_w || !b.fc1_b || !b.fc2_w || !b.fc2_b) return false;
-        }
-        if (!sw_load_conv(m, "l" + std::to_string(i) + ".conv", three, g, m->sw_lconv[i])) return false;
-    }
-    if (!sw_load_conv(m, "cab", three, g, m->sw_cab)) return false;
-    const int nf = 64, oc32 = up32(c.in_chans);
-    auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
-    auto bb = [&](const char* n, int N) { return (const float*)wptr(m, n, true, (size_t)up32(N) * 4); };
-    if (c.upsampler == 0) {
-        m->sw_last_w = c3("last_w", g.Cp, c.in_chans); m->sw_last_b = bb("last_b", c.in_chans);
-        return m->sw_last_w && m->sw_last_b;
-    }
-    m->sw_cbu_w = c3("cbu_w", g.Cp, nf); m->sw_cbu_b = bb("cbu_b", nf);
-    const int n_up = c.upscale == 4 ? 2 : (c.upscale == 2 ? 1 : 0);
-    for (int j = 0; j < n_up; ++j) {
-        const std::string n = "up" + std::to_string(j);
-        const int N = c.upsampler == 1 ? 4 * nf : nf;
-        m->sw_up_w[j] = c3((n + "_w").c_str(), nf, N); m->sw_up_b[j] = bb((n + "_b").c_str(), N);
-        if (!m->sw_up_w[j] || !m->sw_up_b[j]) return false;
-    }
-    if (c.upsampler == 2) {
-        m->sw_hr_w = c3("hr_w", nf, nf); m->sw_hr_b = bb("hr_b", nf);
-        if (!m->sw_hr_w || !m->sw_hr_b) return false;
-    }
-    m->sw_last_w = c3("last_w", nf, c.in_chans); m->sw_last_b = bb("last_b", c.in_chans);
-    (void)oc32;
-    return m->sw_cbu_w && m->sw_cbu_b && m->sw_last_w && m->sw_last_b;
-}
-
-int sw_ensure_workspace(ira_model* m, int T, int Hp, int Wp) {
-    if (m->ws && T <= m->ws_T && Hp == m->ws_H && Wp == m->ws_W) return IRA_OK;
-    if (m->ws) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->ws)); m->ws = nullptr; }
-    const ira_swinir_config& c = m->scfg;
-    const SwGeo g = sw_geo(c);
-    const size_t tp = (size_t)T * Hp * Wp, s2 = (size_t)c.upscale * c.upscale;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
-    const size_t o_xp = take(tp * c.in_chans * 4), o_xf = take(tp * g.Cp * 4), o_xa = take(tp * g.Cp * 4), o_xb = take(tp * g.Cp * 4);
-    const size_t o_qkv = take(tp * 3 * g.heads_max * 32 * 2), o_att = take(tp * g.heads_max * 32 * 2), o_hid = take(tp * g.hidp * 2);
-    const size_t o_c1 = take(c.resi_3conv ? tp * g.qp * 4 : 256), o_c2 = take(c.resi_3conv ? tp * g.qp * 4 : 256);
-    const size_t ub = c.upsampler ? tp * s2 * 64 * 4 : 256;
-    const size_t o_ua = take(ub), o_ub = take(ub), o_y = take(tp * s2 * c.in_chans * 4);
-    hipError_t e = hipMalloc((void**)&m->ws, off);
-    if (e != hipSuccess) {
-        m->ws = nullptr; m->ws_T = 0;
-        return m->fail(IRA_ERR_OOM, "workspace hipMalloc(%zu bytes) for T=%d H=%d W=%d: %s", off, T, Hp, Wp, hipGetErrorString(e));
-    }
-    m->ws_bytes = off; m->ws_T = T; m->ws_H = Hp; m->ws_W = Wp;
-    char* b = m->ws;
-    m->sw_xp = (float*)(b + o_xp); m->sw_xf = (float*)(b + o_xf); m->sw_xa = (float*)(b + o_xa); m->sw_xb = (float*)(b + o_xb);
-    m->sw_qkv = b + o_qkv; m->sw_att = b + o_att; m->sw_hid = b + o_hid;
-    m->sw_c1 = (float*)(b + o_c1); m->sw_c2 = (float*)(b + o_c2); m->sw_ua = (float*)(b + o_ua); m->sw_ub = (float*)(b + o_ub);
-    m->sw_y = (float*)(b + o_y);
-    return IRA_OK;
-}
-
-// y (may alias skip) = resi_conv(x) + skip   ('1conv' / '3conv')
-int sw_resi_conv(ira_model* m, const SConv& cv, const float* x, const float* skip, float* y, int T, int H, int W, const char* fam) {
-    const ira_swinir_config& c = m->scfg;
-    const SwGeo g = sw_geo(c);
-    hipStream_t st = m->st;
-    if (!c.resi_3conv) {
-        RUN(m, fam, ira::launch_conv3x3(st, x, cv.w0, cv.b0, skip, y, 3, T, H, W, g.Cp, g.Cp, g.Cp / 32));
-        return IRA_OK;
-    }
-    RUN(m, fam, ira::launch_conv3x3(st, x, cv.w0, cv.b0, nullptr, m->sw_c1, 4, T, H, W, g.Cp, g.qp, g.qp / 32, 0.2f));
-    RUN(m, fam, ira::launch_naf_pw(st, 3, 0, m->sw_c1, g.qp, cv.w2, 0, cv.b2, nullptr, m->sw_c2, g.qp, g.qp / 32, T, H, W));
-    RUN(m, fam, ira::launch_lrelu(st, m->sw_c2, (long)T * H * W * g.qp, 0.2f));
-    RUN(m, fam, ira::launch_conv3x3(st, m->sw_c2, cv.w4, cv.b4, skip, y, 3, T, H, W, g.qp, g.Cp, g.Cp / 32));
-    return IRA_OK;
-}
-
-int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
-    const ira_swinir_config& c = m->scfg;
-    const SwGeo g = sw_geo(c);
-    const int ws = c.window_size, s = c.upscale, ic = c.in_chans;
-    if (T <= 0 || H <= 0 || W <= 0) return m->fail(IRA_ERR_ARG, "forward: T=%d H=%d W=%d must be positive", T, H, W);
-    const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;                       // check_image_size :783-788
-    if (Hp - H >= H || Wp - W >= W) return m->fail(IRA_ERR_ARG, "reflect padding needs pad < image size (F.pad 'reflect')");
-    int rc = sw_ensure_workspace(m, T, Hp, Wp);
-    if (rc != IRA_OK) return rc;
-    hipStream_t st = m->st;
-    const int P = Hp * Wp;
-    static const float rgb_mean[3] = {0.4488f, 0.4371f, 0.4040f};                             // :659-662
-    static const float zero_mean[3] = {0.f, 0.f, 0.f};
-    const float* mean = ic == 3 ? rgb_mean : zero_mean;
-    RUN(m, "swin_pre", ira::launch_swin_pre(st, in, m->sw_xp, T, H, W, Hp, Wp, ic, mean, c.img_range));                      // :807-810
-    RUN(m, "swin_conv_first", ira::launch_embed(st, m->sw_xp, m->sw_first_w, m->sw_first_b, m->sw_xf, T, Hp, Wp, ic, g.Cp));   // :814
-    RUN(m, "swin_layernorm", ira::launch_ln_affine(st, m->sw_xf, m->sw_pe_g, m->sw_pe_b, m->sw_xa, (long)T * P, g.C, g.Cp, 1e-5f));   // :792
-    char k_[5][64];
-    for (int i = 0; i < c.n_layers; ++i) {
-        const int heads = c.num_heads[i], Kh = heads * 32;
-        if (m->profile) {
-            const char* fam[5] = {"swin_ln_qkv", "swin_window_attn", "swin_proj_res", "swin_ln_fc1_gelu", "swin_fc2_res"};
-            for (int q = 0; q < 5; ++q) snprintf(k_[q], sizeof k_[q], "%s|C%d|%dx%d|T%d", fam[q], g.C, Hp, Wp, T);
-        } else {
-            for (int q = 0; q < 5; ++q) k_[q][0] = 0;
-        }
-        HIP_TRY(m, hipMemcpyAsync(m->sw_xb, m->sw_xa, (size_t)T * P * g.Cp * 4, hipMemcpyDeviceToDevice, st));     // RSTB keeps its input (:482)
-        float* x = m->sw_xb;
-        for (int k = 0; k < c.depths[i]; ++k) {
-            const SBlk& b = m->sw_blocks[i][k];
-            const int shift = (k % 2 == 0) ? 0 : ws / 2;                                                             // :385-386
-            RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0));
-            RUN(m, k_[1], ira::launch_swin_attn(st, m->sw_qkv, b.bias_tab, m->sw_att, T, Hp, Wp, heads, ws, shift));
-            RUN(m, k_[2], ira::launch_pw_nres(st, m->sw_att, Kh, nullptr, 0, false, b.proj_w, 0, b.proj_b, x, x, g.Cp, g.Cp / 32, T, P));
-            RUN(m, k_[3], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.fc1_w, b.fc1_b, m->sw_hid, g.hidp, g.hidp, g.hidp / 32, T, P, 1e-5f, g.C, 1));
-            RUN(m, k_[4], ira::launch_pw_nres(st, m->sw_hid, g.hidp, nullptr, 0, false, b.fc2_w, 0, b.fc2_b, x, x, g.Cp, g.Cp / 32, T, P));
-        }
-        if ((rc = sw_resi_conv(m, m->sw_lconv[i], x, m->sw_xa, m->sw_xa, T, Hp, Wp, "swin_rstb_conv"))) return rc;
-    }
-    RUN(m, "swin_layernorm", ira::launch_ln_affine(st, m->sw_xa, m->sw_norm_g, m->sw_norm_b, m->sw_xb, (long)T * P, g.C, g.Cp, 1e-5f));  // :800
-    if ((rc = sw_resi_conv(m, m->sw_cab, m->sw_xb, m->sw_xf, m->sw_xa, T, Hp, Wp, "swin_conv_after_body"))) return rc;                    // + x_first
-    const float* body = m->sw_xa;
-    const int nb64 = 2, nbo = up32(ic) / 32;
-    int Ho = Hp, Wo = Wp;
-    if (c.upsampler == 0) {                                                                                          // :835-837
-        RUN(m, "swin_conv_last", ira::launch_conv3x3(st, body, m->sw_last_w, m->sw_last_b, m->sw_xp, m->sw_y, 3, T, Hp, Wp, g.Cp, ic, nbo));
-    } else {
-        float *ua = m->sw_ua, *ub = m->sw_ub;
-        RUN(m, "swin_conv_before_upsample", ira::launch_conv3x3(st, body, m->sw_cbu_w, m->sw_cbu_b, nullptr, ua, 4, T, Hp, Wp, g.Cp, 64, nb64, 0.01f));
-        const int n_up = s == 4 ? 2 : (s == 2 ? 1 : 0);
-        for (int j = 0; j < n_up; ++j) {
-            if (c.upsampler == 1) {                                                                                  // Upsample :580-592
-                RUN(m, "swin_upsample_conv_shuffle", ira::launch_conv3x3(st, ua, m->sw_up_w[j], m->sw_up_b[j], nullptr, ub, 2, T, Ho, Wo, 64, 256, 8));
-                std::swap(ua, ub);
-            } else {                                                                                                 // :830-833
-                RUN(m, "swin_nearest2x", ira::launch_nearest2x(st, ua, ub, T, Ho, Wo, 64));
-                RUN(m, "swin_conv_up", ira::launch_conv3x3(st, ub, m->sw_up_w[j], m->sw_up_b[j], nullptr, ua, 4, T, 2 * Ho, 2 * Wo, 64, 64, nb64, 0.2f));
-            }
-            Ho *= 2; Wo *= 2;
-        }
-        if (c.upsampler == 2) {
-            RUN(m, "swin_conv_hr", ira::launch_conv3x3(st, ua, m->sw_hr_w, m->sw_hr_b, nullptr, ub, 4, T, Ho, Wo, 64, 64, nb64, 0.2f));
-            std::swap(ua, ub);
-        }
-        RUN(m, "swin_conv_last", ira::launch_conv3x3(st, ua, m->sw_last_w, m->sw_last_b, nullptr, m->sw_y, 0, T, Ho, Wo, 64, ic, nbo));
-    }
-    RUN(m, "swin_post", ira::launch_swin_post(st, m->sw_y, out, T, Ho, Wo, H * s, W * s, ic, mean, c.img_range));   // :838-840
-    return IRA_OK;
-}
+namespace {
 
 int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
     if (m->arch == 3) return sw_forward_enqueue(m, in, T, H, W, out);
@@ -991,7 +202,7 @@ int ira_model_create(int device, const ira_restormer_config* cfg, const void* bl
     int rc = create_common(device, blob, bytes, &m);
     if (rc != IRA_OK) return rc;
     m->arch = 0; m->cfg = *cfg;
-    if (!bind_weights(m)) {
+    if (!restormer_bind_weights(m)) {
         g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
         ira_model_destroy(m);
         return IRA_ERR_WEIGHTS;
