@@ -21,61 +21,13 @@
 // Numerics contract identical to the three-kernel path (ira_kernels.hip): fp16 LN output, fp16 hidden (hp) and gated
 // (g) values, weights as fp16 hi+lo planes, fp32 accumulation / LN statistics / dwconv / GELU.
 #include "ira_kernels.h"
+#include "ira_device.h"
 
 #include <cstdlib>
 
 namespace ira {
 
-typedef _Float16 f16;
-typedef f16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define IRA_DEV __device__ __forceinline__
-
 namespace {
-
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() also waits vmcnt(0): every chunk would then wait for the
-// consumers' global STORES to be acknowledged and would drain the producers' weight prefetches (measured with
-// s_memtime: 4.1k cycles per chunk for ~350 VALU instructions).  The LDS traffic only needs lgkmcnt(0) + s_barrier.
-IRA_DEV void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-IRA_DEV long xcd_swz(long bid, long nblk) {
-    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
-    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-}
-
-IRA_DEV float gelu_erf_f(float x) {   // same formulation as ira_kernels.hip
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = p * t * __expf(-z * z);
-    return 0.5f * x * ((x >= 0.f) ? (2.0f - e) : e);
-}
-
-// acc += (float)half(lo/hi 16 bits of `packed`) * w     -- v_fma_mix_f32: fp16 source 0, fp32 sources 1 and 2.
-// One instruction instead of v_cvt_f32_f16 + v_fma_f32 (the converts were half of the VALU work of the depthwise
-// conv and kept 32 extra registers live).
-IRA_DEV void fma_mix_lo(float& acc, unsigned packed, float w) {
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
-}
-IRA_DEV void fma_mix_hi(float& acc, unsigned packed, float w) {
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
-}
-IRA_DEV void dw_tap(float (&acc)[8], const u32x4 v, const f32x4 wl, const f32x4 wh) {
-    fma_mix_lo(acc[0], v[0], wl[0]); fma_mix_hi(acc[1], v[0], wl[1]);
-    fma_mix_lo(acc[2], v[1], wl[2]); fma_mix_hi(acc[3], v[1], wl[3]);
-    fma_mix_lo(acc[4], v[2], wh[0]); fma_mix_hi(acc[5], v[2], wh[1]);
-    fma_mix_lo(acc[6], v[3], wh[2]); fma_mix_hi(acc[7], v[3], wh[3]);
-}
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PHW = PH * PW;   // 340 halo pixels
 constexpr int NG1 = (PHW + 31) / 32;                                        // 11 pixel groups
@@ -110,7 +62,7 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
-    const long pid = xcd_swz(blockIdx.x, gridDim.x);
+    const long pid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int t = (int)(pid / ((long)npy * npx));
     const int py = (int)((pid / npx) % npy), pxx = (int)(pid % npx);
     const int y0 = py * TH, x0 = pxx * TW;
@@ -330,7 +282,7 @@ __global__ __launch_bounds__(512) void k_ffn_fused(const float* __restrict__ x, 
             }
             half8 fA, fB;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { fA[e] = (f16)(gelu_erf_f(a1[e]) * a2[e]); fB[e] = (f16)(gelu_erf_f(b1[e]) * b2[e]); }
+            for (int e = 0; e < 8; ++e) { fA[e] = (f16)(gelu_erf(a1[e]) * a2[e]); fB[e] = (f16)(gelu_erf(b1[e]) * b2[e]); }
 #pragma unroll
             for (int nb = 0; nb < NBC; ++nb) {
                 accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh[nb], fA, accA[nb], 0, 0, 0);

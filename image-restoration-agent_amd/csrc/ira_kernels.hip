@@ -25,55 +25,12 @@
 //      channels of ITS pixel -> 16/32-byte NHWC stores, and the registers are already the B fragment
 //      (k = 16s + 8h + j) of a following MFMA that contracts over these channels.
 #include "ira_kernels.h"
+#include "ira_device.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace ira {
-
-typedef _Float16 f16;
-typedef f16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define IRA_DEV __device__ __forceinline__
-
-// XCD-aware work order (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin
-// over the 8 XCDs, each with its own L2.  Remap so that every XCD walks one CONTIGUOUS chunk of the
-// logical (tile, row, x) order: vertically adjacent patches then meet in the same L2 (the 3x3 halo
-// re-reads cost 3-6x HBM/fabric traffic without this, profiles/r01_v2_*).  Bijective for any block count.
-IRA_DEV long xcd_swizzle(long bid, long nblk) {
-    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
-    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-}
-
-IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
-
-IRA_DEV half8 cvt8(const f32x4 lo, const f32x4 hi) {
-    half8 o;
-    o[0] = (f16)lo[0]; o[1] = (f16)lo[1]; o[2] = (f16)lo[2]; o[3] = (f16)lo[3];
-    o[4] = (f16)hi[0]; o[5] = (f16)hi[1]; o[6] = (f16)hi[2]; o[7] = (f16)hi[3];
-    return o;
-}
-
-IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; return z; }
-
-IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
-
-// Exact-erf GELU (F.gelu default, restormer_arch.py:91): 0.5 x (1 + erf(x / sqrt 2)).
-// erfc(|z|) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), used as 1+erf(z) = erfc(-z) so that the
-// negative tail has no cancellation; branch-free: one v_rcp, one v_exp, six FMAs.
-IRA_DEV float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = p * t * __expf(-z * z);            // erfc(|z|)
-    const float one_plus_erf = (x >= 0.f) ? (2.0f - e) : e;
-    return 0.5f * x * one_plus_erf;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Pointwise (1x1) conv, "K-resident": all K input channels of the wave's 32 pixels stay in
@@ -609,7 +566,6 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
     }
 }
 
-typedef f16 half4 __attribute__((ext_vector_type(4)));
 constexpr int DW_PX = 4;   // pixels per thread: 4 x 8 register block (8 x 8 ran at 1 wave/SIMD)
 
 __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, const float* __restrict__ w,
@@ -748,25 +704,6 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Attention matrix, two small kernels (restormer_arch.py:121-131 re-associated).
-// (1) k_attn_softmax, block = (tile, head, 8 q-rows): reduce the S partial Grams in fixed order (bitwise
-//     reproducible), cosine-normalise (F.normalize eps 1e-12, :121-122), * temperature (:124), softmax over
-//     the key channel (:125) -> attn fp32 [T][heads][c][c].
-// (2) k_attn_fold, block = (tile, head, 16 output rows): fold project_out (:131)
-//        M[o][hd*c + j] = sum_i Wo[o][hd*c + i] * attn[i][j]      so that project_out(attn @ v) == conv1x1(v, M)
-//     M: fp16 fragment-major [T][2][NB][C/16][64][8] (hi plane, lo plane); rows >= C are never written (they
-//     only feed MFMA rows that are never stored).
-IRA_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-IRA_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 __global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ part, const float* __restrict__ temp,
                                                       float* __restrict__ attn, int T, int C, int heads, int S) {

@@ -14,36 +14,12 @@
 // k_naf_pw<.., IN_F32, OUT_SHUFFLE_ADD> (weight rows permuted by the packer so that 8 consecutive rows are 8
 // consecutive channels of ONE sub-pixel).
 #include "ira_kernels.h"
+#include "ira_device.h"
 
 namespace ira {
 
-typedef _Float16 f16;
-typedef f16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define IRA_DEV __device__ __forceinline__
-
 namespace {
 
-IRA_DEV long xcd_swz(long bid, long nblk) {
-    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
-    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-}
-IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
-IRA_DEV half8 cvt8(const f32x4 lo, const f32x4 hi) {
-    half8 o;
-    o[0] = (f16)lo[0]; o[1] = (f16)lo[1]; o[2] = (f16)lo[2]; o[3] = (f16)lo[3];
-    o[4] = (f16)hi[0]; o[5] = (f16)hi[1]; o[6] = (f16)hi[2]; o[7] = (f16)hi[3];
-    return o;
-}
-IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; return z; }
-IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
-IRA_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3, IN_SCALED = 4 };
 enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
@@ -229,7 +205,7 @@ __global__ __launch_bounds__(256) void k_naf_dw_sg(const f16* __restrict__ in, c
                                                    float* __restrict__ part, int T, int H, int W, int c, int bpt) {
     __shared__ float sm[256][9];              // +1: conflict-free column reads
     const int XB = (W + NDW_PX - 1) / NDW_PX, G = c >> 3;
-    const long bid = xcd_swz(blockIdx.x, gridDim.x);
+    const long bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int t = (int)(bid / bpt), blk = (int)(bid % bpt);
     const int tid = threadIdx.x;
     const long idx = (long)blk * 256 + tid;
@@ -342,7 +318,7 @@ __global__ __launch_bounds__(256) void k_naf_tail(const f16* __restrict__ g, con
 
     const int chunks = (P + 31) >> 5;
     const int wg_per_tile = (chunks + 4 * TAIL_ITER - 1) / (4 * TAIL_ITER);
-    const long bid = xcd_swz(blockIdx.x, gridDim.x);
+    const long bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int t = (int)(bid / wg_per_tile);
     const int ch0 = (int)(bid % wg_per_tile) * 4 * TAIL_ITER + wave * TAIL_ITER;
     const float* sc = scale + (long)t * C;

@@ -10,54 +10,11 @@
 // v_fma_mix_f32 on 4-pixel x 8-channel register blocks (256 blocks per chunk = one per consumer lane) and
 // store q,k / v directly in the layouts the Gram and attention-apply kernels read.
 #include "ira_kernels.h"
+#include "ira_device.h"
 
 namespace ira {
 
-typedef _Float16 f16;
-typedef f16 half8 __attribute__((ext_vector_type(8)));
-typedef f16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define IRA_DEV __device__ __forceinline__
-
 namespace {
-
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() also waits vmcnt(0): every chunk would then wait for the
-// consumers' global STORES to be acknowledged and would drain the producers' weight prefetches (measured with
-// s_memtime: 4.1k cycles per chunk for ~350 VALU instructions).  The LDS traffic only needs lgkmcnt(0) + s_barrier.
-IRA_DEV void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-IRA_DEV long xcd_swz(long bid, long nblk) {
-    const long q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
-    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-}
-
-IRA_DEV void fma_mix_lo(float& acc, unsigned packed, float w) {
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
-}
-IRA_DEV void fma_mix_hi(float& acc, unsigned packed, float w) {
-    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
-}
-IRA_DEV void dw_tap(float (&acc)[8], const u32x4 v, const f32x4 wl, const f32x4 wh) {
-#ifdef IRA_NO_FMA_MIX
-    const half8 hv = *(const half8*)&v;
-    acc[0] = fmaf((float)hv[0], wl[0], acc[0]); acc[1] = fmaf((float)hv[1], wl[1], acc[1]);
-    acc[2] = fmaf((float)hv[2], wl[2], acc[2]); acc[3] = fmaf((float)hv[3], wl[3], acc[3]);
-    acc[4] = fmaf((float)hv[4], wh[0], acc[4]); acc[5] = fmaf((float)hv[5], wh[1], acc[5]);
-    acc[6] = fmaf((float)hv[6], wh[2], acc[6]); acc[7] = fmaf((float)hv[7], wh[3], acc[7]);
-    return;
-#endif
-    fma_mix_lo(acc[0], v[0], wl[0]); fma_mix_hi(acc[1], v[0], wl[1]);
-    fma_mix_lo(acc[2], v[1], wl[2]); fma_mix_hi(acc[3], v[1], wl[3]);
-    fma_mix_lo(acc[4], v[2], wh[0]); fma_mix_hi(acc[5], v[2], wh[1]);
-    fma_mix_lo(acc[6], v[3], wh[2]); fma_mix_hi(acc[7], v[3], wh[3]);
-}
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PHW = PH * PW;   // 340 halo pixels
 constexpr int NG1 = (PHW + 31) / 32;                                        // 11 pixel groups
@@ -85,7 +42,7 @@ __global__ __launch_bounds__(512) void k_qkv_fused(const float* __restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
-    const long pid = xcd_swz(blockIdx.x, gridDim.x);
+    const long pid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int t = (int)(pid / ((long)npy * npx));
     const int py = (int)((pid / npx) % npy), pxx = (int)(pid % npx);
     const int y0 = py * TH, x0 = pxx * TW;

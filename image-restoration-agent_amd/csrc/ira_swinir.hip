@@ -11,26 +11,9 @@
 //   x  += fc2(h)                    k_pw_nres
 // plus LayerNorm alone (patch_embed.norm, the final norm), the mean/range pre/post maps, nearest-neighbour x2 and LeakyReLU.
 #include "ira_kernels.h"
+#include "ira_device.h"
 
 namespace ira {
-
-typedef _Float16 f16;
-typedef f16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define IRA_DEV __device__ __forceinline__
-
-namespace {
-IRA_DEV int rowperm(int i) { return 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3); }
-IRA_DEV half8 zero8() { half8 z; for (int j = 0; j < 8; ++j) z[j] = (f16)0.f; return z; }
-IRA_DEV f32x16 zero16() { f32x16 z; for (int j = 0; j < 16; ++j) z[j] = 0.f; return z; }
-IRA_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // (Shifted-)window multi-head self attention (:114-145 inside :239-279), one wave per (image, window, head).
