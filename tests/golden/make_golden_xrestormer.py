@@ -1,0 +1,66 @@
+"""Golden fixtures for X-Restormer FROM THE REFERENCE MODULE (dev container only).  xrestormer_arch.py imports
+``basicsr.utils.registry.ARCH_REGISTRY`` (used as a class decorator) and ``torchstat.stat`` (used only under __main__):
+1-symbol stubs are injected, as SURVEY 8c describes."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'image-restoration-agent_amd'))
+sys.path.insert(0, ROOT)
+from ira_amd.xrestormer import XRestormerConfig, reduced_xrestormer_config, seeded_state_dict      # noqa: E402
+from ira_amd.synth import synthetic_noisy_image                                                   # noqa: E402
+
+REF = '/root/reference/AgenticIR/executor/dehazing/tools/X-Restormer/xrestormer/archs/xrestormer_arch.py'
+
+
+def load_ref():
+    class _Reg:
+        def register(self, *a, **k):
+            return lambda cls: cls
+    for name in ('basicsr', 'basicsr.utils', 'basicsr.utils.registry', 'torchstat'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['basicsr.utils.registry'].ARCH_REGISTRY = _Reg()
+    sys.modules['torchstat'].stat = lambda *a, **k: None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_xrestormer_arch', REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    torch.set_num_threads(8)
+    mod = load_ref()
+    spec = {}
+    cases = {'reduced_64': (reduced_xrestormer_config(), 1, 64, 64, 1),
+             'reduced_biasfree_bias_64x128': (reduced_xrestormer_config(LayerNorm_type='BiasFree', bias=True), 2, 64, 128, 2),
+             'full_64': (XRestormerConfig(), 3, 64, 64, 1)}
+    for name, (cfg, seed, H, W, B) in cases.items():
+        m = mod.XRestormer(**cfg.to_dict()).eval()
+        sd = seeded_state_dict(cfg, seed)
+        ref_names = [k for k, _ in m.state_dict().items()]
+        assert ref_names == list(sd.keys()), (name, [a for a in ref_names if a not in sd][:5], [a for a in sd if a not in ref_names][:5],
+                                               next((i, a, b) for i, (a, b) in enumerate(zip(ref_names, sd.keys())) if a != b) if set(ref_names) == set(sd) else None)
+        spec[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        _, noisy = synthetic_noisy_image(H, W, 3, sigma=25.0, seed=500 + seed)
+        x = torch.from_numpy(noisy).float().div(255.).permute(2, 0, 1).unsqueeze(0).contiguous()
+        if B > 1:
+            x = torch.cat([x, x.flip(-1)], 0)
+        with torch.no_grad():
+            y = m(x)
+        np.savez_compressed(os.path.join(HERE, f'xrestormer_{name}.npz'), cfg=json.dumps(cfg.to_dict()), seed=seed,
+                            input=x.numpy(), output=y.numpy().astype(np.float32))
+        print(name, tuple(y.shape), float(y.abs().max()), float((y - x).std()), sum(p.numel() for p in m.parameters()))
+    with open(os.path.join(HERE, 'xrestormer_state_dict_spec.json'), 'w') as f:
+        json.dump({k: v for k, v in spec.items() if k != 'full_64'}, f)
+
+
+if __name__ == '__main__':
+    main()
