@@ -98,4 +98,8 @@ hipError_t launch_swin_post(hipStream_t st, const float* in, float* out, int T, 
 hipError_t launch_nearest2x(hipStream_t st, const float* in, float* out, int T, int H, int W, int C);
 hipError_t launch_lrelu(hipStream_t st, float* x, long n, float slope);
 
+// ---- X-Restormer (ira_xrestormer.hip): overlapping cross-attention, window 8 / overlap window 12 / head_dim 16.
+// qkv fp16 [T][H][W][3*heads*16] (q | k | v), rel fp32 [2][32][16] (rel_width rows 0..22, then rel_height), out fp16 [T][H][W][heads*16]
+hipError_t launch_ocab_attn(hipStream_t st, const void* qkv, const float* rel, void* out, int T, int H, int W, int heads);
+
 }  // namespace ira

@@ -23,6 +23,13 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
     const void* pin_w = nullptr;  const float* pin_b = nullptr;
     const float* dw2_w = nullptr; const float* dw2_b = nullptr;
     const void* pout_w = nullptr; const float* pout_b = nullptr;
+    // X-Restormer only (xrestormer_arch.py:239-262): OCAB and the second GDFN; level = index into spatial_heads
+    int level = 0;
+    const void* oc_qkv_w = nullptr; const float* oc_qkv_b = nullptr; const float* oc_rel = nullptr;
+    const void* oc_proj_w = nullptr; const float* oc_proj_b = nullptr;
+    const void* pin2_w = nullptr; const float* pin2_b = nullptr;
+    const float* dw3_w = nullptr; const float* dw3_b = nullptr;
+    const void* pout2_w = nullptr; const float* pout2_b = nullptr;
 };
 
 struct Prof { long launches = 0; double ms = 0; };
@@ -56,6 +63,8 @@ struct ira_model {
     int device = -1;
     int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR
     ira_restormer_config cfg{};
+    bool xr = false;                 // arch 0 with X-Restormer blocks
+    int xr_spatial_heads[4] = {0, 0, 0, 0};
     ira_nafnet_config ncfg{};
     ira_dncnn_config dcfg{};
     ira_swinir_config scfg{};

@@ -25,7 +25,7 @@ static int gram_splits(int T, int heads, long nblk) {
     return (int)std::max(1L, std::min(nsteps / 64, 64L));
 }
 
-static bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, Blk& b) {
+static bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, int level, Blk& b) {
     const size_t NBq = up32(3 * C), NBc = up32(C);
     const bool cb = m->cfg.conv_bias != 0, lb = m->cfg.ln_with_bias != 0;
     m->err.clear();
@@ -42,13 +42,28 @@ static bool load_block(ira_model* m, const std::string& p, int C, int heads, int
     b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
     b.pout_w = wptr(m, p + ".pout_w", true, 2 * NBc * Hp * 2);
     b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
+    b.level = level;
+    if (m->xr) {    // X-Restormer: OCAB (xrestormer_arch.py:190-236) + the second GDFN
+        const size_t inner = 16 * (size_t)m->xr_spatial_heads[level], NBo = up32(3 * (int)inner);
+        b.oc_qkv_w = wptr(m, p + ".oc_qkv_w", true, 2 * NBo * C * 2);
+        b.oc_qkv_b = (const float*)wptr(m, p + ".oc_qkv_b", cb || lb, NBo * 4);
+        b.oc_rel = (const float*)wptr(m, p + ".oc_rel", true, (size_t)2 * 32 * 16 * 4);
+        b.oc_proj_w = wptr(m, p + ".oc_proj_w", true, 2 * NBc * inner * 2);
+        b.oc_proj_b = (const float*)wptr(m, p + ".oc_proj_b", cb, NBc * 4);
+        b.pin2_w = wptr(m, p + ".pin2_w", true, (size_t)2 * 2 * Hp * C * 2);
+        b.pin2_b = (const float*)wptr(m, p + ".pin2_b", cb || lb, (size_t)2 * Hp * 4);
+        b.dw3_w = (const float*)wptr(m, p + ".dw3_w", true, (size_t)9 * 2 * Hp * 4);
+        b.dw3_b = (const float*)wptr(m, p + ".dw3_b", cb, (size_t)2 * Hp * 4);
+        b.pout2_w = wptr(m, p + ".pout2_w", true, 2 * NBc * Hp * 2);
+        b.pout2_b = (const float*)wptr(m, p + ".pout2_b", cb, NBc * 4);
+    }
     return m->err.empty();
 }
 
-static bool load_stage(ira_model* m, const char* name, int n, int C, int heads, int Hp, std::vector<Blk>& out) {
+static bool load_stage(ira_model* m, const char* name, int n, int C, int heads, int Hp, int level, std::vector<Blk>& out) {
     out.resize(n);
     for (int i = 0; i < n; ++i)
-        if (!load_block(m, std::string(name) + "." + std::to_string(i), C, heads, Hp, out[i])) return false;
+        if (!load_block(m, std::string(name) + "." + std::to_string(i), C, heads, Hp, level, out[i])) return false;
     return true;
 }
 
@@ -59,15 +74,15 @@ bool restormer_bind_weights(ira_model* m) {
     m->err.clear();
     m->embed_w = (const float*)wptr(m, "embed_w", true, (size_t)c.dim * c.inp_channels * 9 * 4);
     if (!m->embed_w) return false;
-    if (!load_stage(m, "encoder_level1", c.num_blocks[0], g.C[0], g.heads[0], g.Hp[0], m->enc1)) return false;
-    if (!load_stage(m, "encoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->enc2)) return false;
-    if (!load_stage(m, "encoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->enc3)) return false;
-    if (!load_stage(m, "latent", c.num_blocks[3], g.C[3], g.heads[3], g.Hp[3], m->lat)) return false;
-    if (!load_stage(m, "decoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], m->dec3)) return false;
-    if (!load_stage(m, "decoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], m->dec2)) return false;
+    if (!load_stage(m, "encoder_level1", c.num_blocks[0], g.C[0], g.heads[0], g.Hp[0], 0, m->enc1)) return false;
+    if (!load_stage(m, "encoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], 1, m->enc2)) return false;
+    if (!load_stage(m, "encoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], 2, m->enc3)) return false;
+    if (!load_stage(m, "latent", c.num_blocks[3], g.C[3], g.heads[3], g.Hp[3], 3, m->lat)) return false;
+    if (!load_stage(m, "decoder_level3", c.num_blocks[2], g.C[2], g.heads[2], g.Hp[2], 2, m->dec3)) return false;
+    if (!load_stage(m, "decoder_level2", c.num_blocks[1], g.C[1], g.heads[1], g.Hp[1], 1, m->dec2)) return false;
     // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
-    if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], m->dec1)) return false;
-    if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], m->refine)) return false;
+    if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], 0, m->dec1)) return false;
+    if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], 0, m->refine)) return false;
     auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
     m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
     m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
@@ -140,17 +155,43 @@ static int ensure_workspace(ira_model* m, int T, int H, int W) {
     return IRA_OK;
 }
 
+// GDFN + residual (restormer_arch.py:88-93,149): fused kernel where supported (writes x -> alt, the two are swapped), else three kernels
+static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const float* dw_w, const float* dw_b, const void* pout_w,
+                   const float* pout_b, float*& x, float*& alt, int T, int H, int W, int C, int Hp) {
+    const int P = H * W, NBc = up32(C) / 32;
+    const int ln = m->cfg.ln_with_bias ? 2 : 1;
+    hipStream_t st = m->st;
+    char k_[3][64];
+    if (m->profile) {
+        const char* fam[3] = {"ln_pin_1x1", "dwconv_gate", "pout_res"};
+        for (int i = 0; i < 3; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
+    } else {
+        for (int i = 0; i < 3; ++i) k_[i][0] = 0;
+    }
+    if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
+        char kf[64];
+        if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
+        RUN(m, kf, ira::launch_ffn_fused(st, x, alt, ln, C, pin_w, pin_b, dw_w, dw_b, pout_w, pout_b, T, H, W, Hp));
+        std::swap(x, alt);
+        return IRA_OK;
+    }
+    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, pin_w, pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
+    RUN(m, k_[1], ira::launch_dwconv_gate(st, m->hp, dw_w, dw_b, m->g, T, H, W, Hp));
+    RUN(m, k_[2], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, pout_w, 0, pout_b, x, x, C, NBc, T, P));
+    return IRA_OK;
+}
+
 // ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
 // x: current residual stream buffer; alt: a second buffer of the same size (or nullptr).  The fused FFN writes
 // x -> alt and the two are swapped, so on return x still names the buffer holding the block's output.
 static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp) {
     const int P = H * W;
-    char k_[8][64];
+    char k_[5][64];
     if (m->profile) {
-        const char* fam[8] = {"ln_qkv_1x1", "dwconv_qkv", "gram", "attn_mix", "attn_apply_res", "ln_pin_1x1", "dwconv_gate", "pout_res"};
-        for (int i = 0; i < 8; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
+        const char* fam[5] = {"ln_qkv_1x1", "dwconv_qkv", "gram", "attn_mix", "attn_apply_res"};
+        for (int i = 0; i < 5; ++i) snprintf(k_[i], sizeof k_[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
     } else {
-        for (int i = 0; i < 8; ++i) k_[i][0] = 0;
+        for (int i = 0; i < 5; ++i) k_[i][0] = 0;
     }
     const int ln = m->cfg.ln_with_bias ? 2 : 1;
     const int NBq = up32(3 * C) / 32, NBc = up32(C) / 32;
@@ -170,17 +211,21 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
     RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
     // GDFN (:88-93)
-    if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
-        char kf[64];
-        if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
-        RUN(m, kf, ira::launch_ffn_fused(st, x, alt, ln, C, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, T, H, W, Hp));
-        std::swap(x, alt);
-        return IRA_OK;
+    int rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp);
+    if (rc != IRA_OK || !m->xr) return rc;
+    // X-Restormer (xrestormer_arch.py:260-261): x += OCAB(norm3(x)); x += spatial_ffn(norm4(x))
+    const int sheads = m->xr_spatial_heads[b.level], inner = 16 * sheads, NBo = up32(3 * inner) / 32;
+    char ko[3][64];
+    if (m->profile) {
+        const char* fam[3] = {"ocab_ln_qkv", "ocab_attn", "ocab_proj_res"};
+        for (int i = 0; i < 3; ++i) snprintf(ko[i], sizeof ko[i], "%s|C%d|%dx%d|T%d", fam[i], C, H, W, T);
+    } else {
+        for (int i = 0; i < 3; ++i) ko[i][0] = 0;
     }
-    RUN(m, k_[5], ira::launch_pw_kres(st, x, true, ln, C, b.pin_w, b.pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
-    RUN(m, k_[6], ira::launch_dwconv_gate(st, m->hp, b.dw2_w, b.dw2_b, m->g, T, H, W, Hp));
-    RUN(m, k_[7], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, b.pout_w, 0, b.pout_b, x, x, C, NBc, T, P));
-    return IRA_OK;
+    RUN(m, ko[0], ira::launch_pw_kres(st, x, true, ln, C, b.oc_qkv_w, b.oc_qkv_b, m->qkvp, 3 * inner, 3 * inner, NBo, T, P));
+    RUN(m, ko[1], ira::launch_ocab_attn(st, m->qkvp, b.oc_rel, m->v, T, H, W, sheads));
+    RUN(m, ko[2], ira::launch_pw_nres(st, m->v, inner, nullptr, 0, false, b.oc_proj_w, 0, b.oc_proj_b, x, x, C, NBc, T, P));
+    return run_ffn(m, b.pin2_w, b.pin2_b, b.dw3_w, b.dw3_b, b.pout2_w, b.pout2_b, x, alt, T, H, W, C, Hp);
 }
 
 static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp) {
@@ -196,6 +241,8 @@ int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W
     const ira_restormer_config& c = m->cfg;
     if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
         return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);
+    if (m->xr && ((H & 63) || (W & 63)))
+        return m->fail(IRA_ERR_ARG, "X-Restormer forward: H=%d W=%d must be multiples of 64 (8x8 windows on the 1/8 level; the harness pads, xrestormer_model.py:53-63)", H, W);
     int rc = ensure_workspace(m, T, H, W);
     if (rc != IRA_OK) return rc;
     const Geo g = make_geo(c, H, W);

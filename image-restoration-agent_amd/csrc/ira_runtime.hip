@@ -212,6 +212,42 @@ int ira_model_create(int device, const ira_restormer_config* cfg, const void* bl
 }
 
 
+int ira_xrestormer_create(int device, const ira_xrestormer_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_xrestormer_create: NULL argument");
+    *out = nullptr;
+    if (cfg->window_size != 8 || cfg->spatial_dim_head != 16) return gfail(IRA_ERR_ARG, "window_size 8 and spatial_dim_head 16 are the built configuration");
+    for (int l = 0; l < 4; ++l) {
+        if (cfg->overlap_win[l] != 12) return gfail(IRA_ERR_ARG, "overlap window must be 12 (overlap_ratio 0.5), got %d at level %d", cfg->overlap_win[l], l);
+        if (cfg->spatial_heads[l] < 1 || 16 * cfg->spatial_heads[l] > (cfg->base.dim << l))
+            return gfail(IRA_ERR_ARG, "level %d: spatial_heads %d out of range", l, cfg->spatial_heads[l]);
+    }
+    if (cfg->scale != 1) return gfail(IRA_ERR_ARG, "scale %d is not built (only 1)", cfg->scale);
+    ira_model_t* m = nullptr;
+    // the Restormer part (U-Net, channel attention, GDFN) is validated and set up by the Restormer constructor; binding is redone
+    // with the X entries below, so build the handle in two steps
+    ira_restormer_config base = cfg->base;
+    if (base.dual_pixel_task) return gfail(IRA_ERR_ARG, "dual_pixel_task is not supported");
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 0; m->cfg = base; m->xr = true;
+    for (int l = 0; l < 4; ++l) m->xr_spatial_heads[l] = cfg->spatial_heads[l];
+    // same structural checks as ira_model_create
+    bool ok = base.dim > 0 && base.dim % 16 == 0 && base.inp_channels == base.out_channels && (base.inp_channels == 1 || base.inp_channels == 3);
+    for (int l = 0; l < 4 && ok; ++l) {
+        const int C = base.dim << l;
+        ok = base.heads[l] > 0 && C % base.heads[l] == 0 && (C / base.heads[l] == 16 || C / base.heads[l] == 32 || C / base.heads[l] == 48 || C / base.heads[l] == 96) && base.hidden[l] > 0;
+    }
+    if (ok) { const int c1 = 2 * base.dim / base.heads[0]; ok = (2 * base.dim) % base.heads[0] == 0 && (c1 == 16 || c1 == 32 || c1 == 48 || c1 == 96); }
+    if (!ok) { ira_model_destroy(m); return gfail(IRA_ERR_ARG, "unsupported dim / channel_heads combination (per-head channels must be 16, 32, 48 or 96)"); }
+    if (!restormer_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
+    *out = m;
+    return IRA_OK;
+}
+
 int ira_nafnet_create(int device, const ira_nafnet_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
     if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_nafnet_create: NULL argument");
     *out = nullptr;
@@ -651,6 +687,10 @@ int ira_op_naf_dw_sg(ira_model_t* m, const void* in, const float* w, const float
                      int W, int c, int* blocks_per_image) {
     if (blocks_per_image) *blocks_per_image = ira::naf_dw_sg_blocks(H, W, c);
     OP_BODY(m, "op", ira::launch_naf_dw_sg(m->st, in, w, bias, out, part, T, H, W, c));
+}
+
+int ira_op_ocab_attn(ira_model_t* m, const void* qkv, const float* rel, void* out, int T, int H, int W, int heads) {
+    OP_BODY(m, "op", ira::launch_ocab_attn(m->st, qkv, rel, out, T, H, W, heads));
 }
 
 int ira_op_swin_attn(ira_model_t* m, const void* qkv, const float* bias, void* out, int T, int H, int W, int heads, int ws, int shift) {

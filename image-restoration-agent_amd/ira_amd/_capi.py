@@ -25,6 +25,11 @@ class IraConfig(C.Structure):
     ]
 
 
+class IraXrestormerConfig(C.Structure):
+    _fields_ = [('base', IraConfig), ('spatial_heads', C.c_int32 * 4), ('window_size', C.c_int32), ('overlap_win', C.c_int32 * 4),
+                ('spatial_dim_head', C.c_int32), ('scale', C.c_int32)]
+
+
 NAFNET_MAX_LEVELS = 6
 
 
@@ -58,6 +63,7 @@ _pi = C.POINTER(C.c_int)
 SIGNATURES = {
     'ira_device_count': (_i, [_pi]),
     'ira_model_create': (_i, [_i, C.POINTER(IraConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_xrestormer_create': (_i, [_i, C.POINTER(IraXrestormerConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_nafnet_create': (_i, [_i, C.POINTER(IraNafnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_dncnn_create': (_i, [_i, C.POINTER(IraDncnnConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_swinir_create': (_i, [_i, C.POINTER(IraSwinirConfig), _vp, _sz, C.POINTER(_vp)]),
@@ -93,6 +99,7 @@ SIGNATURES = {
     'ira_op_pw_kres_eps': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float]),
     'ira_op_naf_pw': (_i, [_vp, _i, _i, _vp, _i, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ira_op_naf_dw_sg': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _pi]),
+    'ira_op_ocab_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     'ira_op_swin_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     'ira_op_ln_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, C.c_float]),
     'ira_op_pw_kres_ex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i]),

@@ -210,3 +210,13 @@ class SwinIRBackend(_Backend):
         self.cfg = cfg
         self.scale = cfg.upscale
         self._create(device, 'ira_swinir_create', swinir_cfg_struct(cfg), pack_swinir_blob(state_dict, cfg), 'ira_swinir_create')
+
+
+class XRestormerBackend(_Backend):
+    """One X-Restormer on one MI355X (SURVEY 8 row f1; xrestormer_arch.py:324-422).  ``forward`` needs H, W multiples of 64;
+    ``restore_padcrop(img, tile_size, tile_pad, padding_size=64)`` is its harness (xrestormer_model.py:53-136)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .xrestormer import pack_xrestormer_blob, xrestormer_cfg_struct
+        self.cfg = cfg
+        self._create(device, 'ira_xrestormer_create', xrestormer_cfg_struct(cfg), pack_xrestormer_blob(state_dict, cfg), 'ira_xrestormer_create')

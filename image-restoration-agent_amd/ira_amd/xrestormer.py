@@ -136,3 +136,93 @@ def seeded_tensor(seed, name, shape):
 
 def seeded_state_dict(cfg: XRestormerConfig, seed: int = 0):
     return OrderedDict((n, seeded_tensor(seed, n, s)) for n, s in state_dict_spec(cfg))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# packer: reference state_dict -> device blob.  The Restormer part (U-Net glue, channel attention, first GDFN) goes through
+# ira_amd.pack with the key names translated; the OCAB and the second GDFN are added per block.
+
+def restormer_equivalent(cfg: XRestormerConfig):
+    from .config import RestormerConfig
+    return RestormerConfig(inp_channels=cfg.inp_channels, out_channels=cfg.out_channels, dim=cfg.dim, num_blocks=list(cfg.num_blocks),
+                           num_refinement_blocks=cfg.num_refinement_blocks, heads=list(cfg.channel_heads),
+                           ffn_expansion_factor=cfg.ffn_expansion_factor, bias=cfg.bias, LayerNorm_type=cfg.LayerNorm_type,
+                           dual_pixel_task=cfg.dual_pixel_task)
+
+
+def xrestormer_cfg_struct(cfg: XRestormerConfig):
+    from ._capi import IraXrestormerConfig
+    from .backend import _cfg_struct
+    if cfg.scale != 1:
+        raise ValueError("scale > 1 (the SR preset's bilinear pre-upsampling) is not built")
+    s = IraXrestormerConfig()
+    s.base = _cfg_struct(restormer_equivalent(cfg))
+    for l in range(4):
+        s.spatial_heads[l] = cfg.spatial_heads[l]
+        s.overlap_win[l] = cfg.overlap_win(l)
+    s.window_size, s.spatial_dim_head, s.scale = cfg.window_size, cfg.spatial_dim_head, cfg.scale
+    return s
+
+
+def pack_xrestormer_arrays(sd, cfg: XRestormerConfig) -> dict:
+    from .pack import pack_arrays, frag_major, split16, up32, _np, _pad_rows, _hidden_remap, _dw_pack
+    rcfg = restormer_equivalent(cfg)
+    tr = {}
+    for k, v in sd.items():
+        if '.spatial_attn.' in k or '.spatial_ffn.' in k or '.norm3.' in k or '.norm4.' in k:
+            continue
+        tr[k.replace('.channel_attn.', '.attn.').replace('.channel_ffn.', '.ffn.')] = v
+    out = pack_arrays(tr, rcfg)
+    wb = cfg.LayerNorm_type != 'BiasFree'
+    dh = cfg.spatial_dim_head
+    f64 = lambda k: _np(sd[k]).astype(np.float64)
+    for name, n, dim, lvl in _stages(cfg):
+        heads = cfg.spatial_heads[lvl]
+        inner, hid, r = dh * heads, cfg.hidden(dim), cfg.overlap_win(lvl)
+        hp = up32(hid)
+        for i in range(n):
+            p, o = f'{name}.{i}', f'{name}.{i}'
+            g3, g4 = f64(f'{p}.norm3.body.weight'), f64(f'{p}.norm4.body.weight')
+            wq = f64(f'{p}.spatial_attn.qkv.weight')[:, :, 0, 0]                      # [3*inner][dim]: q | k | v
+            scale = np.ones(3 * inner)
+            scale[:inner] = dh ** -0.5                                                 # xrestormer_arch.py:199,225
+            out[f'{o}.oc_qkv_w'] = frag_major(split16(_pad_rows(wq * g3[None, :] * scale[:, None], up32(3 * inner))))
+            bq = np.zeros(3 * inner)
+            has_b = False
+            if wb:
+                bq += wq @ f64(f'{p}.norm3.body.bias'); has_b = True
+            if cfg.bias:
+                bq += f64(f'{p}.spatial_attn.qkv.bias'); has_b = True
+            if has_b:
+                out[f'{o}.oc_qkv_b'] = _pad_rows((bq * scale).astype(np.float32), up32(3 * inner))
+            rel = np.zeros((2, 32, dh), np.float32)
+            rel[0, :2 * r - 1] = _np(sd[f'{p}.spatial_attn.rel_pos_emb.rel_width'])
+            rel[1, :2 * r - 1] = _np(sd[f'{p}.spatial_attn.rel_pos_emb.rel_height'])
+            out[f'{o}.oc_rel'] = rel
+            wo = np.zeros((up32(dim), inner), np.float64)
+            wo[:dim] = f64(f'{p}.spatial_attn.project_out.weight')[:, :, 0, 0]
+            out[f'{o}.oc_proj_w'] = frag_major(split16(wo))
+            wi = f64(f'{p}.spatial_ffn.project_in.weight')[:, :, 0, 0]
+            out[f'{o}.pin2_w'] = frag_major(split16(_hidden_remap(wi * g4[None, :], hid, hp)))
+            bi = np.zeros(2 * hid)
+            has_b = False
+            if wb:
+                bi += wi @ f64(f'{p}.norm4.body.bias'); has_b = True
+            if cfg.bias:
+                bi += f64(f'{p}.spatial_ffn.project_in.bias'); has_b = True
+            if has_b:
+                out[f'{o}.pin2_b'] = _hidden_remap(bi.astype(np.float32), hid, hp)
+            out[f'{o}.dw3_w'] = _dw_pack(_hidden_remap(_np(sd[f'{p}.spatial_ffn.dwconv.weight']), hid, hp))
+            wout = np.zeros((up32(dim), hp), np.float64)
+            wout[:dim, :hid] = f64(f'{p}.spatial_ffn.project_out.weight')[:, :, 0, 0]
+            out[f'{o}.pout2_w'] = frag_major(split16(wout))
+            if cfg.bias:
+                out[f'{o}.oc_proj_b'] = _pad_rows(_np(sd[f'{p}.spatial_attn.project_out.bias']).astype(np.float32), up32(dim))
+                out[f'{o}.dw3_b'] = _hidden_remap(_np(sd[f'{p}.spatial_ffn.dwconv.bias']).astype(np.float32), hid, hp)
+                out[f'{o}.pout2_b'] = _pad_rows(_np(sd[f'{p}.spatial_ffn.project_out.bias']).astype(np.float32), up32(dim))
+    return out
+
+
+def pack_xrestormer_blob(sd, cfg: XRestormerConfig) -> bytes:
+    from .pack import blob_from_arrays
+    return blob_from_arrays(pack_xrestormer_arrays(sd, cfg))

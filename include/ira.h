@@ -57,6 +57,18 @@ typedef struct ira_restormer_config {
     int32_t dual_pixel_task;         /* must be 0 (not dispatched by the agent) */
 } ira_restormer_config;
 
+/* Constructor arguments of the reference XRestormer (X-Restormer/xrestormer/archs/xrestormer_arch.py:325-341): the Restormer
+ * fields (base.heads = channel_heads) plus the overlapping cross-attention parameters.  Built: window_size 8,
+ * overlap_ratio 0.5 (overlap window 12), spatial_dim_head 16, scale 1. */
+typedef struct ira_xrestormer_config {
+    ira_restormer_config base;
+    int32_t spatial_heads[4];        /* {1,2,4,8} in the test presets (options/test/00x_xrestormer_*.yml) */
+    int32_t window_size;             /* 8 */
+    int32_t overlap_win[4];          /* int(window_size * overlap_ratio) + window_size = 12 */
+    int32_t spatial_dim_head;        /* 16 */
+    int32_t scale;                   /* 1 */
+} ira_xrestormer_config;
+
 /* Constructor arguments of the reference NAFNet (X-Restormer/xrestormer/archs/NAFNet_arch.py:251): SURVEY 8 row a11 /
  * BASELINE config 2.  n_levels = len(enc_blk_nums) == len(dec_blk_nums). */
 #define IRA_NAFNET_MAX_LEVELS 6
@@ -106,6 +118,11 @@ int ira_device_count(int* count);
  * model.load_state_dict(...); model.eval()  (demo.py:95-103, model_serving.py:101-124). */
 int ira_model_create(int device, const ira_restormer_config* cfg,
                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* X-Restormer (blob from ira_amd/xrestormer.py::pack_xrestormer_blob): forward needs H, W multiples of 64; its harness is
+ * ira_restore_padcrop_u8 (padding_size 64).  replaces XRestormer(**opt['network_g']) + load_state_dict (xrestormer_arch.py:324-374). */
+int ira_xrestormer_create(int device, const ira_xrestormer_config* cfg,
+                          const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+
 /* Same for NAFNet (blob from ira_amd/nafnet.py::pack_nafnet_blob).  The returned handle is used with the same
  * ira_forward / ira_forward_device / measurement / ira_model_destroy entry points; for NAFNet they accept any H, W
  * (the network zero-pads to a multiple of 2^n_levels and crops: NAFNet_arch.py:303,326,356-361).
@@ -275,6 +292,11 @@ int ira_op_concat2(ira_model_t* m, const float* a_dev, int Ca, const float* b_de
 int ira_op_pw_kres_eps(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K,
                        const void* W_f16_dev, const float* bias_dev, void* y_f16_dev, int y_stride,
                        int n_store, int NB, int T, int P, float eps);
+
+/* ---- X-Restormer kernel: overlapping cross-attention core of OCAB (xrestormer_arch.py:209-232 with RelPosEmb :64-82):
+ * qkv fp16 (T,H,W,3*heads*16) = q | k | v (q pre-scaled), rel fp32 [2][32][16] (rel_width rows 0..22, rel_height rows 0..22 of
+ * the second tile), out fp16 (T,H,W,heads*16).  8x8 query windows, 12x12 zero-padded key windows. */
+int ira_op_ocab_attn(ira_model_t* m, const void* qkv_dev, const float* rel_dev, void* out_dev, int T, int H, int W, int heads);
 
 /* ---- SwinIR kernels (network_swinir.py)
  * (Shifted-)window attention, one call = roll(-shift) + window_partition + WindowAttention core + window_reverse + roll(+shift)
