@@ -307,6 +307,89 @@ class SwinIR(Tool):
         self._postprocess()
 
 
+# X-Restormer tool: subtask -> (checkpoint, padding_size) of executor/<subtask>/configs/xrestormer.yml.  The super_resolution config
+# (sr_300k.pth, scale 4: bilinear pre-upsampling, xrestormer_arch.py:378-379) is not built.
+XRESTORMER_OPTS = {
+    'denoising': ('denoise_300k.pth', 64), 'dehazing': ('dehaze_300k.pth', 64),
+    'motion_deblurring': ('deblur_300k.pth', 64), 'deraining': ('derain_155k.pth', 64),
+}
+
+
+def default_xrestormer_loader(model_name: str, weight_dir: Optional[str] = None):
+    """basicsr's load_network(strict) of ``path.pretrain_network_g`` (param key 'params' when present).  Looks in ``weight_dir``
+    or $IRA_XRESTORMER_WEIGHTS (the reference's X-Restormer/experiments/pretrained directory)."""
+    root = weight_dir or os.environ.get('IRA_XRESTORMER_WEIGHTS', '')
+    path = os.path.join(root, model_name)
+    if not (root and os.path.isfile(path)):
+        raise FileNotFoundError(f"X-Restormer weights {model_name!r} not found in {root!r}; set IRA_XRESTORMER_WEIGHTS or pass a loader")
+    import torch
+    ckpt = torch.load(path, map_location='cpu')
+    for key in ('params_ema', 'params'):
+        if key in ckpt:
+            return ckpt[key]
+    return ckpt
+
+
+class XRestormerCache:
+    """checkpoint name -> XRestormerBackend on one device (every preset shares one architecture)."""
+
+    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
+                 backend_factory: Optional[Callable] = None):
+        self.device, self.weight_dir = device, weight_dir
+        self.loader = state_dict_loader or default_xrestormer_loader
+        self.factory = backend_factory
+        self.models: dict = {}
+
+    def get(self, model_name: str):
+        if model_name not in self.models:
+            from .xrestormer import XRestormerConfig
+            cfg = XRestormerConfig()                         # network_g of the configs: identical for the four presets
+            sd = self.loader(model_name, self.weight_dir)
+            if self.factory is not None:
+                self.models[model_name] = self.factory(cfg, sd, self.device)
+            else:
+                from .backend import XRestormerBackend
+                self.models[model_name] = XRestormerBackend(cfg, sd, device=self.device)
+        return self.models[model_name]
+
+    def close(self):
+        for be in self.models.values():
+            if hasattr(be, 'close'):
+                be.close()
+        self.models.clear()
+
+
+_default_xrestormer_cache: Optional[XRestormerCache] = None
+
+
+def default_xrestormer_cache() -> XRestormerCache:
+    global _default_xrestormer_cache
+    if _default_xrestormer_cache is None:
+        _default_xrestormer_cache = XRestormerCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+    return _default_xrestormer_cache
+
+
+class XRestormer(Tool):
+    """X-Restormer tool for denoising, dehazing, motion deblurring and deraining (multitask_tools.py:66-78 on the BasicSRModel
+    base :8-63), in-process.  The reference writes a BasicSR config and spawns ``inference.py -opt cfg.yml``; the config has no
+    ``tile`` section, so the image is reflect-padded to a multiple of 64 and run whole (xrestormer_model.py:53-63,138-150)."""
+
+    def __init__(self, subtask: str, cache: Optional[XRestormerCache] = None, tile_size: Optional[int] = None, tile_pad: int = 32):
+        super().__init__(tool_name="xrestormer", subtask=subtask, work_dir="X-Restormer", script_rel_path=Path("xrestormer") / 'inference.py')
+        sub = canonical_subtask(subtask)
+        if sub not in XRESTORMER_OPTS:
+            raise KeyError(f"X-Restormer on the HIP backend handles {sorted(XRESTORMER_OPTS)} (super_resolution needs scale 4), not {subtask!r}")
+        self.model_name, self.padding_size = XRESTORMER_OPTS[sub]
+        self._cache = cache
+        self.tile_size, self.tile_pad = tile_size, tile_pad
+
+    def _invoke(self, *args) -> None:
+        be = (self._cache or default_xrestormer_cache()).get(self.model_name)
+        src = sorted(Path(self.input_dir).glob('*'))[0]
+        out = be.restore_padcrop(read_image(src, gray=False), tile_size=self.tile_size, tile_pad=self.tile_pad, padding_size=self.padding_size)
+        write_png(Path(self.output_dir) / 'output.png', out)
+
+
 class Executor:
     """Registry of toolboxes (executor/__init__.py:24-94,161-169)."""
 
@@ -358,21 +441,27 @@ RESTORMER_SUBTASKS = {
 }
 
 
-def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None) -> Executor:
+def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
+                   xrestormer_cache: Optional[XRestormerCache] = None) -> Executor:
     """The tools this backend provides, under the reference's subtask keys and in the reference's toolbox order
     (executor/denoising/__init__.py:12-19, super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39)."""
     ex = Executor()
     for key, sub in RESTORMER_SUBTASKS.items():
         ex.register_subtask(key, [Restormer(subtask=sub, cache=cache)])
     ex.toolbox_router['denoising'] = [SwinIR('denoising', '15', swinir_cache), SwinIR('denoising', '50', swinir_cache)] + ex.toolbox_router['denoising']
+    for key, sub in (('denoising', 'denoising'), ('motion deblurring', 'motion_deblurring'), ('deraining', 'deraining')):
+        ex.toolbox_router[key] = [XRestormer(sub, xrestormer_cache)] + ex.toolbox_router[key]      # first in every reference toolbox it is in
+    ex.register_subtask('dehazing', [XRestormer('dehazing', xrestormer_cache)])
     ex.register_subtask('super-resolution', [SwinIR('super_resolution', 'gan', swinir_cache), SwinIR('super_resolution', 'psnr', swinir_cache)])
     ex.register_subtask('jpeg compression artifact removal', [SwinIR('jpeg_compression_artifact_removal', '40', swinir_cache)])
     return ex
 
 
-def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None) -> int:
-    """Drop-in: replace every tool named 'restormer' or 'swinir_*' in an existing (reference) executor's toolboxes by
-    the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.  Returns the count."""
+def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
+                 xrestormer_cache: Optional[XRestormerCache] = None) -> int:
+    """Drop-in: replace every tool named 'restormer', 'swinir_*' or 'xrestormer' (except the scale-4 SR one) in an existing
+    (reference) executor's toolboxes by the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.
+    Returns the count."""
     n = 0
     for key, toolbox in reference_executor.toolbox_router.items():
         for i, tool in enumerate(toolbox):
@@ -380,6 +469,9 @@ def install_into(reference_executor, cache: Optional[BackendCache] = None, swini
             sub = canonical_subtask(getattr(tool, 'subtask', key))
             if name == 'restormer':
                 toolbox[i] = Restormer(subtask=sub, cache=cache)
+                n += 1
+            elif name == 'xrestormer' and sub in XRESTORMER_OPTS:
+                toolbox[i] = XRestormer(subtask=sub, cache=xrestormer_cache)
                 n += 1
             elif name.startswith('swinir_') and sub in SWINIR_OPTS and name[7:] in SWINIR_OPTS[sub][1]:
                 toolbox[i] = SwinIR(subtask=sub, pretrained_on=name[7:], cache=swinir_cache)

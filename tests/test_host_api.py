@@ -69,16 +69,18 @@ def test_subtask_to_task(subtask, task, cache):
 def test_executor_registry_and_directory_protocol(tmp_path, cache):
     ex = T.build_executor(cache)
     assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining', 'super-resolution',
-                           'jpeg compression artifact removal'}
-    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['swinir_15', 'swinir_50', 'restormer']     # reference order
+                           'jpeg compression artifact removal', 'dehazing'}
+    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['xrestormer', 'swinir_15', 'swinir_50', 'restormer']     # reference order
+    assert [t.tool_name for t in ex.toolbox_router['motion deblurring']] == ['xrestormer', 'restormer']
+    assert [t.tool_name for t in ex.toolbox_router['dehazing']] == ['xrestormer']
     assert [t.tool_name for t in ex.toolbox_router['super-resolution']] == ['swinir_gan', 'swinir_psnr']
     assert [t.tool_name for t in ex.toolbox_router['jpeg compression artifact removal']] == ['swinir_40']
     root = tmp_path / 'task'
     (root / '0-img').mkdir(parents=True)
     img = _img(seed=3)
     Image.fromarray(img).save(root / '0-img' / 'input.png')
-    outp = ex.execute_subtask('motion deblurring', root / '0-img' / 'input.png')     # executor/__init__.py:40-85
-    assert outp == root / 'subtask1-motion_deblurring' / 'tool1-restormer' / '0-img' / 'output.png'
+    outp = ex.execute_subtask('defocus deblurring', root / '0-img' / 'input.png')     # executor/__init__.py:40-85
+    assert outp == root / 'subtask1-defocus_deblurring' / 'tool1-restormer' / '0-img' / 'output.png'
     assert ex.executed_subtask_cnt == 1
     o2 = tmp_path / 'o2'; o2.mkdir()
     ex.invoke_a_tool('denoising', 'restormer', root / '0-img', o2)
@@ -93,9 +95,12 @@ def test_install_into_reference_executor(cache):
     class RefExecutor:
         toolbox_router = {'denoising': [RefTool('xrestormer', 'denoising'), RefTool('restormer', 'denoising')],
                           'dehazing': [RefTool('maxim', 'dehazing')]}
-        toolbox_router['super-resolution'] = [RefTool('diffbir', 'super_resolution'), RefTool('swinir_gan', 'super_resolution')]
+        toolbox_router['super-resolution'] = [RefTool('diffbir', 'super_resolution'), RefTool('swinir_gan', 'super_resolution'),
+                                              RefTool('xrestormer', 'super_resolution')]
     n = T.install_into(RefExecutor, cache)
-    assert n == 2
+    assert n == 3          # restormer, swinir_gan, xrestormer(denoising); the scale-4 xrestormer of super-resolution stays
+    assert isinstance(RefExecutor.toolbox_router['denoising'][0], T.XRestormer)
+    assert not isinstance(RefExecutor.toolbox_router['super-resolution'][2], T.XRestormer)
     tb = RefExecutor.toolbox_router['denoising']
     assert tb[0].tool_name == 'xrestormer' and isinstance(tb[1], T.Restormer) and tb[1].opt_task == 'Real_Denoising'
     sr = RefExecutor.toolbox_router['super-resolution']
@@ -246,3 +251,30 @@ def test_swinir_service_api():
         svc.process_image(bgr, m, 2, 8)
     miss = SS.SwinIRService(model_path='/nonexistent.pth')
     assert miss.load_model('color_dn')[1].startswith('Model file not found')
+
+
+def test_xrestormer_tool_contract(tmp_path):
+    """multitask_tools.py:66-78 + the subtask configs: name, checkpoint per subtask, untiled pad-to-64 harness call."""
+    calls = []
+
+    class FakeX:
+        def __init__(self, cfg, sd, device):
+            self.cfg, self.sd = cfg, sd
+
+        def restore_padcrop(self, img, tile_size=None, tile_pad=32, padding_size=64):
+            calls.append((img.shape, tile_size, tile_pad, padding_size))
+            return 255 - img
+    xc = T.XRestormerCache(state_dict_loader=lambda name, wd: name, backend_factory=FakeX)
+    tool = T.XRestormer('dehazing', cache=xc)
+    assert (tool.tool_name, tool.subtask, tool.model_name, tool.padding_size) == ('xrestormer', 'dehazing', 'dehaze_300k.pth', 64)
+    inp, out = tmp_path / 'in', tmp_path / 'out'
+    inp.mkdir(); out.mkdir()
+    img = _img(21, 30)
+    Image.fromarray(img).save(inp / 'input.png')
+    tool(inp, out, silent=True)
+    assert os.listdir(out) == ['output.png'] and np.array_equal(np.asarray(Image.open(out / 'output.png')), 255 - img)
+    assert calls == [((21, 30, 3), None, 32, 64)]
+    assert xc.get('dehaze_300k.pth').cfg.spatial_heads == [1, 2, 4, 8] and xc.get('dehaze_300k.pth').sd == 'dehaze_300k.pth'
+    assert T.XRestormer('deraining', cache=xc).model_name == 'derain_155k.pth'
+    with pytest.raises(KeyError):
+        T.XRestormer('super_resolution', cache=xc)
