@@ -346,9 +346,104 @@ def main_swinir(args):
         dist.destroy_process_group()
 
 
+def main_xrestormer(args):
+    """X-Restormer (the agent's `xrestormer` tool runs whole images padded to a multiple of 64): one 1280x720 frame
+    = (1, 768, 1280, 3) float32 NHWC resident in HBM through the network, output in HBM.  N > 1: independent replicas."""
+    import numpy as np
+    import torch
+    from ira_amd.backend import XRestormerBackend
+    from ira_amd.xrestormer import XRestormerConfig, seeded_state_dict
+    from ira_amd.synth import synthetic_noisy_image
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cfg = XRestormerConfig()
+    be = XRestormerBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
+    H, W = 768, 1280
+    _, noisy = synthetic_noisy_image(H, W, 3, sigma=25.0, seed=rank)
+    x = torch.from_numpy(noisy).float().div(255.).unsqueeze(0).contiguous().to(dev)
+    y = torch.empty_like(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        be.sync()
+
+    for _ in range(args.warmup):
+        be.forward_device(x.data_ptr(), 1, H, W, y.data_ptr())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        be.forward_device(x.data_ptr(), 1, H, W, y.data_ptr())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        be.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    step_s = elapsed / args.steps
+    result = {'metric': 'restored megapixels/sec (X-Restormer, 1280x720 frame padded to 768 rows, whole image)',
+              'value': round(world * H * W / 1e6 / step_s, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+              'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+              'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic',
+              'config': {'workload': 'X-Restormer dim 48, blocks [2,4,4,4]+4, channel/spatial heads [1,2,4,8] (26.0M params, seeded weights), '
+                                     f'(1, {H}, {W}, 3) float32 per GPU per step'}}
+    if world == 1 and not args.no_kernel_profile:
+        be.profile_enable(True)
+        be.forward_device(x.data_ptr(), 1, H, W, y.data_ptr())
+        prof = be.profile()
+        be.profile_enable(False)
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f, indent=1, sort_keys=True)
+        tot = sum(v['ms'] for v in prof.values())
+        fam_tot = {}
+        for k, v in prof.items():
+            fam_tot[k.split('|')[0]] = fam_tot.get(k.split('|')[0], 0.0) + v['ms']
+        key = max(prof, key=lambda k: prof[k]['ms'])
+        result['roofline'] = {'bound': 'hbm', 'kernel': key, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                              'avg_launch_ms': round(prof[key]['ms'] / prof[key]['launches'], 4), 'share_of_step': round(prof[key]['ms'] / tot, 4)}
+        result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
+        result['kernel_ms_total_profiled'] = round(tot, 3)
+    else:
+        result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.xrestormer_oracle import xrestormer_forward
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        xc = x[:, :128, :128].cpu().permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            xrestormer_forward(xc, sd, cfg.to_dict())
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                xrestormer_forward(xc, sd, cfg.to_dict())
+            dt = (time.perf_counter() - t1) / reps
+        result['cpu_baseline'] = {'value': round(128 * 128 / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+                                  'sample': f'oracle/xrestormer_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one 128x128 crop after 1 warm-up ({dt:.2f} s each)'}
+    print(json.dumps(result), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4'],
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4', 'xrestormer720p'],
                     help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = configs[1]; swinir_x4 = configs[3]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -366,6 +461,8 @@ def main():
         return main_nafnet(args)
     if args.workload == 'swinir_x4':
         return main_swinir(args)
+    if args.workload == 'xrestormer720p':
+        return main_xrestormer(args)
 
     import numpy as np
     import torch

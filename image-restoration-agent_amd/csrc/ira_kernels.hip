@@ -643,14 +643,20 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
 // part: fp32 [T][S][heads][c*c + 2c]: gram[qi][kj], then sum q^2 [c], then sum k^2 [c].
 template <int CT>
 __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float* __restrict__ part, int T,
-                                              int nblk, int C, int heads, int S) {
+                                              int nblk, int C, int heads, int S, int bands) {
+    // bands (a divisor of CT): the q-channel tiles of one (tile, head, split) are shared out over `bands` waves.  Every output
+    // element still accumulates the same pixels in the same order, so the result does not depend on `bands`; the launcher
+    // uses it to fill the chip when there are few tiles (a whole 720p image at heads = 1 had 64 waves for 1024 SIMDs).
     constexpr int c = CT * 16;
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (long)T * heads * S) return;
+    const long wv0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv0 >= (long)T * heads * S * bands) return;
+    const int band = (int)(wv0 % bands);
+    const long wv = wv0 / bands;
     const int s = (int)(wv % S);
     const int hd = (int)((wv / S) % heads);
     const int t = (int)(wv / ((long)S * heads));
+    const int per = CT / bands, i_lo = band * per, i_hi = i_lo + per;
 
     f32x4 acc[CT][CT];
     float nq[CT], nk[CT];
@@ -669,7 +675,8 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
         half8 a[CT], b[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            a[i] = ok ? *(const half8*)(bp + (long)(16 * i) * 8) : zero8();
+            const bool mine = i >= i_lo && i < i_hi;             // wave-uniform
+            a[i] = (ok && mine) ? *(const half8*)(bp + (long)(16 * i) * 8) : zero8();
             b[i] = ok ? *(const half8*)(bp + (long)(C + 16 * i) * 8) : zero8();
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -679,31 +686,36 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
             }
         }
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CT; ++i) {
+            if (i >= i_lo && i < i_hi) {
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
     }
     float* dst = part + (((long)t * S + s) * heads + hd) * (c * c + 2 * c);
     // D layout 16x16: col = lane & 15 (k channel), row = 4*(lane>>4) + reg (q channel)
 #pragma unroll
-    for (int i = 0; i < CT; ++i)
+    for (int i = 0; i < CT; ++i) {
+        if (i >= i_lo && i < i_hi) {
 #pragma unroll
-        for (int j = 0; j < CT; ++j)
+            for (int j = 0; j < CT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(16 * i + 4 * lg + e) * c + 16 * j + li] = acc[i][j][e];
+                for (int e = 0; e < 4; ++e) dst[(16 * i + 4 * lg + e) * c + 16 * j + li] = acc[i][j][e];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         float a = nq[i], b = nk[i];
         a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
         b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
         if (lg == 0) {
-            dst[c * c + 16 * i + li] = a;
-            dst[c * c + c + 16 * i + li] = b;
+            if (i >= i_lo && i < i_hi) dst[c * c + 16 * i + li] = a;
+            if (band == 0) dst[c * c + c + 16 * i + li] = b;
         }
     }
 }
-
 
 __global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ part, const float* __restrict__ temp,
                                                       float* __restrict__ attn, int T, int C, int heads, int S) {
@@ -718,21 +730,21 @@ __global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ 
     const int rec = c * c + 2 * c;
     const float* pb = part + ((long)t * S * heads + hd) * rec;
     const long sstride = (long)heads * rec;
-    for (int idx = tid; idx < nrows * c; idx += 256) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += pb[s * sstride + (long)i0 * c + idx];
-        L[idx] = a;
-    }
-    for (int idx = tid; idx < c; idx += 256) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += pb[s * sstride + c * c + c + idx];
-        nks[idx] = a;
-    }
-    if (tid < nrows) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += pb[s * sstride + c * c + i0 + tid];
-        nqs[tid] = a;
-    }
+    // sum of the S partial records in a FIXED order (bitwise reproducible), eight independent chains so that the loads of a
+    // long reduction (S up to 512) overlap instead of waiting for one another
+    auto sum_parts = [&](long off) -> float {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += pb[(long)(s + u) * sstride + off];
+        }
+        for (; s < S; ++s) a[0] += pb[(long)s * sstride + off];
+        return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    };
+    for (int idx = tid; idx < nrows * c; idx += 256) L[idx] = sum_parts((long)i0 * c + idx);
+    for (int idx = tid; idx < c; idx += 256) nks[idx] = sum_parts((long)c * c + c + idx);
+    if (tid < nrows) nqs[tid] = sum_parts((long)c * c + i0 + tid);
     __syncthreads();
     const float tmp = temp[hd];
     for (int row = wave; row < nrows; row += 4) {
@@ -1357,14 +1369,19 @@ hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, co
 
 hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int nblk, int C, int heads, int S) {
     if (heads <= 0 || C % heads != 0 || (C / heads) % 16 != 0 || S <= 0) return hipErrorInvalidValue;
-    const long waves = (long)T * heads * S;
+    const int CT = C / heads / 16;
+    const long waves1 = (long)T * heads * S;
+    int bands = 1;                                   // largest divisor of CT that keeps the launch under ~4096 waves
+    for (int d = 2; d <= CT; ++d)
+        if (CT % d == 0 && waves1 * d <= 4096) bands = d;
+    const long waves = waves1 * bands;
     const dim3 grid(grid1d(waves, 4)), block(256);
     const f16* q = (const f16*)qk;
-    switch (C / heads / 16) {
-        case 1: hipLaunchKernelGGL((k_gram<1>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
-        case 2: hipLaunchKernelGGL((k_gram<2>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
-        case 3: hipLaunchKernelGGL((k_gram<3>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
-        case 6: hipLaunchKernelGGL((k_gram<6>), grid, block, 0, st, q, part, T, nblk, C, heads, S); break;
+    switch (CT) {
+        case 1: hipLaunchKernelGGL((k_gram<1>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
+        case 2: hipLaunchKernelGGL((k_gram<2>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
+        case 3: hipLaunchKernelGGL((k_gram<3>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
+        case 6: hipLaunchKernelGGL((k_gram<6>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
