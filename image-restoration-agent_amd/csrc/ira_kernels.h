@@ -64,7 +64,7 @@ hipError_t launch_blend(hipStream_t st, const float* tiles, int h, int w, int c,
 hipError_t launch_extract_list(hipStream_t st, const uint8_t* frame, int h, int w, int c, int th, int tw, const int* desc,
                                int n_tiles, float* tiles);
 hipError_t launch_scatter_cores(hipStream_t st, const float* tiles, int th, int tw, int c, const int* desc, int n_tiles,
-                                int max_core, int h, int w, uint8_t* out);
+                                int max_core, int h, int w, uint8_t* out, int scale = 1);   // tiles / out on the scale-times finer grid
 
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
 hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int B, int C, int H, int W);
@@ -100,6 +100,7 @@ hipError_t launch_lrelu(hipStream_t st, float* x, long n, float slope);
 
 // ---- X-Restormer (ira_xrestormer.hip): overlapping cross-attention, window 8 / overlap window 12 / head_dim 16.
 // qkv fp16 [T][H][W][3*heads*16] (q | k | v), rel fp32 [2][32][16] (rel_width rows 0..22, then rel_height), out fp16 [T][H][W][heads*16]
+hipError_t launch_bilinear_up(hipStream_t st, const float* in, float* out, int T, int H, int W, int C, int s);
 hipError_t launch_ocab_attn(hipStream_t st, const void* qkv, const float* rel, void* out, int T, int H, int W, int heads);
 
 }  // namespace ira

@@ -1115,24 +1115,25 @@ __global__ __launch_bounds__(256) void k_extract_list(const uint8_t* __restrict_
     }
 }
 
-// core of every tile -> uint8 frame: clamp(0,1), rint(x*255); pixels in the pre_process padding are dropped (:134-136)
+// core of every tile -> uint8 frame: clamp(0,1), rint(x*255); pixels in the pre_process padding are dropped (:134-136).
+// scale s > 1 (SR presets): tiles and the output frame live on the s-times finer grid, desc stays in input coordinates (:117-133).
 __global__ __launch_bounds__(256) void k_scatter_cores(const float* __restrict__ tiles, int th, int tw, int c,
                                                        const int* __restrict__ desc, int n_tiles, int max_core, int h, int w,
-                                                       uint8_t* __restrict__ out) {
-    const long total = (long)n_tiles * max_core * c;
+                                                       uint8_t* __restrict__ out, int s) {
+    const long total = (long)n_tiles * max_core * s * s * c;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % c);
         long rest = idx / c;
-        const int q = (int)(rest % max_core);
-        const int tl = (int)(rest / max_core);
+        const long q = rest % ((long)max_core * s * s);
+        const int tl = (int)(rest / ((long)max_core * s * s));
         const int* d = desc + tl * 6;
-        const int cw = d[5], chh = d[4];
-        if (q >= cw * chh) continue;
-        const int dy = q / cw, dx = q % cw;
-        const int Y = d[2] + dy, X = d[3] + dx;
-        if (Y >= h || X >= w) continue;
-        const float v = tiles[(((long)tl * th + (d[2] - d[0] + dy)) * tw + (d[3] - d[1] + dx)) * c + ch];
-        out[((long)Y * w + X) * c + ch] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
+        const int cw = d[5] * s, chh = d[4] * s;
+        if (q >= (long)cw * chh) continue;
+        const int dy = (int)(q / cw), dx = (int)(q % cw);
+        const int Y = d[2] * s + dy, X = d[3] * s + dx;
+        if (Y >= h * s || X >= w * s) continue;
+        const float v = tiles[(((long)tl * th * s + ((d[2] - d[0]) * s + dy)) * (tw * s) + ((d[3] - d[1]) * s + dx)) * c + ch];
+        out[((long)Y * (w * s) + X) * c + ch] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
     }
 }
 
@@ -1471,9 +1472,9 @@ hipError_t launch_extract_list(hipStream_t st, const uint8_t* frame, int h, int 
 }
 
 hipError_t launch_scatter_cores(hipStream_t st, const float* tiles, int th, int tw, int c, const int* desc, int n_tiles,
-                                int max_core, int h, int w, uint8_t* out) {
-    hipLaunchKernelGGL(k_scatter_cores, dim3(grid1d((long)n_tiles * max_core * c, 256, 65536)), dim3(256), 0, st, tiles, th, tw, c,
-                       desc, n_tiles, max_core, h, w, out);
+                                int max_core, int h, int w, uint8_t* out, int scale) {
+    hipLaunchKernelGGL(k_scatter_cores, dim3(grid1d((long)n_tiles * max_core * scale * scale * c, 256, 65536)), dim3(256), 0, st, tiles, th, tw, c,
+                       desc, n_tiles, max_core, h, w, out, scale);
     return hipGetLastError();
 }
 

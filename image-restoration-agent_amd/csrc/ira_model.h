@@ -65,6 +65,8 @@ struct ira_model {
     ira_restormer_config cfg{};
     bool xr = false;                 // arch 0 with X-Restormer blocks
     int xr_spatial_heads[4] = {0, 0, 0, 0};
+    int xr_scale = 1;                // X-Restormer SR preset: bilinear x4 of the input before the network
+    float* xr_up = nullptr; size_t xr_up_bytes = 0;
     ira_nafnet_config ncfg{};
     ira_dncnn_config dcfg{};
     ira_swinir_config scfg{};

@@ -240,6 +240,18 @@ static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, floa
 
 // ---- Restormer.forward (restormer_arch.py:245-284) on device NHWC fp32, T tiles of H x W (enqueue only)
 int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    if (m->xr && m->xr_scale > 1) {              // xrestormer_arch.py:378-379: the network runs on the bilinearly upsampled input
+        const int s = m->xr_scale;
+        const size_t need = (size_t)T * H * s * W * s * m->cfg.inp_channels * 4;
+        if (need > m->xr_up_bytes) {
+            if (m->xr_up) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->xr_up)); m->xr_up = nullptr; m->xr_up_bytes = 0; }
+            hipError_t e = hipMalloc((void**)&m->xr_up, need);
+            if (e != hipSuccess) { m->xr_up = nullptr; return m->fail(IRA_ERR_OOM, "upsample buffer hipMalloc(%zu): %s", need, hipGetErrorString(e)); }
+            m->xr_up_bytes = need;
+        }
+        RUN(m, "xr_bilinear_up", ira::launch_bilinear_up(m->st, in, m->xr_up, T, H, W, m->cfg.inp_channels, s));
+        in = m->xr_up; H *= s; W *= s;
+    }
     const ira_restormer_config& c = m->cfg;
     if (T <= 0 || H <= 0 || W <= 0 || (H & 7) || (W & 7))
         return m->fail(IRA_ERR_ARG, "forward: H=%d W=%d must be positive multiples of 8 (demo.py:122-127), T=%d", H, W, T);

@@ -221,7 +221,7 @@ int ira_xrestormer_create(int device, const ira_xrestormer_config* cfg, const vo
         if (cfg->spatial_heads[l] < 1 || 16 * cfg->spatial_heads[l] > (cfg->base.dim << l))
             return gfail(IRA_ERR_ARG, "level %d: spatial_heads %d out of range", l, cfg->spatial_heads[l]);
     }
-    if (cfg->scale != 1) return gfail(IRA_ERR_ARG, "scale %d is not built (only 1)", cfg->scale);
+    if (cfg->scale != 1 && cfg->scale != 2 && cfg->scale != 4) return gfail(IRA_ERR_ARG, "scale %d unsupported (1, 2, 4)", cfg->scale);
     ira_model_t* m = nullptr;
     // the Restormer part (U-Net, channel attention, GDFN) is validated and set up by the Restormer constructor; binding is redone
     // with the X entries below, so build the handle in two steps
@@ -229,7 +229,7 @@ int ira_xrestormer_create(int device, const ira_xrestormer_config* cfg, const vo
     if (base.dual_pixel_task) return gfail(IRA_ERR_ARG, "dual_pixel_task is not supported");
     int rc = create_common(device, blob, bytes, &m);
     if (rc != IRA_OK) return rc;
-    m->arch = 0; m->cfg = base; m->xr = true;
+    m->arch = 0; m->cfg = base; m->xr = true; m->xr_scale = cfg->scale;
     for (int l = 0; l < 4; ++l) m->xr_spatial_heads[l] = cfg->spatial_heads[l];
     // same structural checks as ira_model_create
     bool ok = base.dim > 0 && base.dim % 16 == 0 && base.inp_channels == base.out_channels && (base.inp_channels == 1 || base.inp_channels == 3);
@@ -328,6 +328,7 @@ int ira_model_destroy(ira_model_t* m) {
     hipSetDevice(m->device);
     if (m->st) hipStreamSynchronize(m->st);
     if (m->ws) hipFree(m->ws);
+    if (m->xr_up) hipFree(m->xr_up);
     if (m->hs) hipFree(m->hs);
     if (m->wblob) hipFree(m->wblob);
     if (m->ev0) hipEventDestroy(m->ev0);
@@ -369,7 +370,7 @@ int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, flo
     if (B <= 0 || H <= 0 || W <= 0 || (m->arch == 0 && ((H & 7) || (W & 7))))
         return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
     const size_t n = (size_t)B * C * H * W;
-    const int s = m->arch == 3 ? m->scfg.upscale : 1;             // SwinIR SR: the output is (B, C, H*s, W*s)
+    const int s = m->arch == 3 ? m->scfg.upscale : (m->xr ? m->xr_scale : 1);   // SR models: the output is (B, C, H*s, W*s)
     const size_t no = n * s * s;
     int rc = ensure_scratch(m, al256(n * 4) + 2 * al256(no * 4));
     if (rc != IRA_OK) return rc;
@@ -495,12 +496,13 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
             D d{{syp, sxp, sy, sx, ey - sy, ex - sx}};
             classes[{eyp - syp, exp_ - sxp}].push_back(d);
         }
-    if (m->arch == 0)
+    if (m->arch == 0 && !m->xr)
         for (auto& kv : classes)
             if ((kv.first.first & 7) || (kv.first.second & 7))
                 return m->fail(IRA_ERR_ARG, "tile %dx%d is not a multiple of 8: choose tile_size, tile_pad, padding_size as multiples of 8",
                                kv.first.first, kv.first.second);
-    const size_t fbytes = (size_t)h * w * c;
+    const int sc = m->arch == 3 ? m->scfg.upscale : (m->xr ? m->xr_scale : 1);      // tile_process with scale (:72-76,117-133)
+    const size_t fbytes = (size_t)h * w * c, obytes = fbytes * sc * sc;
     uint8_t *fin = nullptr, *fout = nullptr; float *tin = nullptr, *tout = nullptr; int* ddev = nullptr;
     auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tin) hipFree(tin); if (tout) hipFree(tout); if (ddev) hipFree(ddev); };
     size_t max_batch_elems = 0, max_desc = 0;
@@ -514,8 +516,8 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
         max_desc = std::max(max_desc, kv.second.size());
     }
     hipError_t e;
-    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, fbytes)) != hipSuccess ||
-        (e = hipMalloc((void**)&tin, max_batch_elems * 4)) != hipSuccess || (e = hipMalloc((void**)&tout, max_batch_elems * 4)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, obytes)) != hipSuccess ||
+        (e = hipMalloc((void**)&tin, max_batch_elems * 4)) != hipSuccess || (e = hipMalloc((void**)&tout, max_batch_elems * 4 * sc * sc)) != hipSuccess ||
         (e = hipMalloc((void**)&ddev, max_desc * sizeof(D))) != hipSuccess) {
         cleanup();
         return m->fail(IRA_ERR_OOM, "ira_restore_padcrop_u8: hipMalloc: %s", hipGetErrorString(e));
@@ -535,12 +537,12 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
                 rc = run(m, "padcrop_extract", [&]() { return ira::launch_extract_list(m->st, fin, h, w, c, th, tw, ddev + (size_t)t0 * 6, nbt, tin); });
                 if (rc != IRA_OK) break;
                 if ((rc = forward_enqueue(m, tin, nbt, th, tw, tout)) != IRA_OK) break;
-                rc = run(m, "padcrop_scatter", [&]() { return ira::launch_scatter_cores(m->st, tout, th, tw, c, ddev + (size_t)t0 * 6, nbt, max_core, h, w, fout); });
+                rc = run(m, "padcrop_scatter", [&]() { return ira::launch_scatter_cores(m->st, tout, th, tw, c, ddev + (size_t)t0 * 6, nbt, max_core, h, w, fout, sc); });
             }
             if (rc != IRA_OK) break;
         }
         if (rc != IRA_OK) break;
-        if ((e = hipMemcpyAsync(out, fout, fbytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
+        if ((e = hipMemcpyAsync(out, fout, obytes, hipMemcpyDeviceToHost, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "download: %s", hipGetErrorString(e)); break; }
         if ((e = hipStreamSynchronize(m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
     } while (0);
     if (rc != IRA_OK) hipStreamSynchronize(m->st);

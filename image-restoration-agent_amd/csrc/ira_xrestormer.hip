@@ -148,6 +148,36 @@ __global__ __launch_bounds__(256) void k_ocab_attn(const f16* __restrict__ qkv, 
     }
 }
 
+// F.interpolate(scale_factor=s, mode='bilinear', align_corners=False) on fp32 NHWC (the SR preset's first step, xrestormer_arch.py:378-379):
+// source coordinate (dst + 0.5) / s - 0.5 clamped at 0, neighbours clamped at the border, as ATen's upsample_bilinear2d does.
+__global__ __launch_bounds__(256) void k_bilinear_up(const float* __restrict__ in, float* __restrict__ out, int T, int H, int W, int C, int s) {
+    const int Ho = H * s, Wo = W * s;
+    const long total = (long)T * Ho * Wo * C;
+    const float rs = 1.0f / (float)s;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % C);
+        long rest = idx / C;
+        const int x = (int)(rest % Wo); rest /= Wo;
+        const int y = (int)(rest % Ho);
+        const int t = (int)(rest / Ho);
+        const float sy = fmaxf(((float)y + 0.5f) * rs - 0.5f, 0.f), sx = fmaxf(((float)x + 0.5f) * rs - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* b = in + (long)t * H * W * C + ch;
+        out[idx] = hy * (hx * b[((long)y0 * W + x0) * C] + lx * b[((long)y0 * W + x1) * C]) +
+                   ly * (hx * b[((long)y1 * W + x0) * C] + lx * b[((long)y1 * W + x1) * C]);
+    }
+}
+
+hipError_t launch_bilinear_up(hipStream_t st, const float* in, float* out, int T, int H, int W, int C, int s) {
+    if (s < 1) return hipErrorInvalidValue;
+    long g = ((long)T * H * s * W * s * C + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(k_bilinear_up, dim3((unsigned)g), dim3(256), 0, st, in, out, T, H, W, C, s);
+    return hipGetLastError();
+}
+
 hipError_t launch_ocab_attn(hipStream_t st, const void* qkv, const float* rel, void* out, int T, int H, int W, int heads) {
     if (H % OC_WS != 0 || W % OC_WS != 0 || heads <= 0) return hipErrorInvalidValue;
     const long waves = (long)T * (H / OC_WS) * (W / OC_WS) * heads;

@@ -116,7 +116,8 @@ class _Backend:
         if img.dtype != np.uint8 or img.ndim != 3:
             raise ValueError("expected a uint8 (h,w,c) array")
         h, w, c = img.shape
-        out = np.empty_like(img)
+        s = int(getattr(self, 'scale', 1))
+        out = np.empty((h * s, w * s, c), np.uint8)
         rc = self._lib.ira_restore_padcrop_u8(self._h, img.ctypes.data, h, w, c, int(tile_size) if tile_size else 0,
                                               int(tile_pad), int(padding_size), out.ctypes.data)
         self._ck(rc, 'ira_restore_padcrop_u8')
@@ -219,4 +220,5 @@ class XRestormerBackend(_Backend):
     def __init__(self, cfg, state_dict, device: int = 0):
         from .xrestormer import pack_xrestormer_blob, xrestormer_cfg_struct
         self.cfg = cfg
+        self.scale = cfg.scale
         self._create(device, 'ira_xrestormer_create', xrestormer_cfg_struct(cfg), pack_xrestormer_blob(state_dict, cfg), 'ira_xrestormer_create')

@@ -307,11 +307,11 @@ class SwinIR(Tool):
         self._postprocess()
 
 
-# X-Restormer tool: subtask -> (checkpoint, padding_size) of executor/<subtask>/configs/xrestormer.yml.  The super_resolution config
-# (sr_300k.pth, scale 4: bilinear pre-upsampling, xrestormer_arch.py:378-379) is not built.
+# X-Restormer tool: subtask -> (checkpoint, padding_size, scale) of executor/<subtask>/configs/xrestormer.yml
 XRESTORMER_OPTS = {
-    'denoising': ('denoise_300k.pth', 64), 'dehazing': ('dehaze_300k.pth', 64),
-    'motion_deblurring': ('deblur_300k.pth', 64), 'deraining': ('derain_155k.pth', 64),
+    'denoising': ('denoise_300k.pth', 64, 1), 'dehazing': ('dehaze_300k.pth', 64, 1),
+    'motion_deblurring': ('deblur_300k.pth', 64, 1), 'deraining': ('derain_155k.pth', 64, 1),
+    'super_resolution': ('sr_300k.pth', 16, 4),
 }
 
 
@@ -340,10 +340,10 @@ class XRestormerCache:
         self.factory = backend_factory
         self.models: dict = {}
 
-    def get(self, model_name: str):
+    def get(self, model_name: str, scale: int = 1):
         if model_name not in self.models:
             from .xrestormer import XRestormerConfig
-            cfg = XRestormerConfig()                         # network_g of the configs: identical for the four presets
+            cfg = XRestormerConfig(scale=scale)              # network_g of the configs: identical apart from scale
             sd = self.loader(model_name, self.weight_dir)
             if self.factory is not None:
                 self.models[model_name] = self.factory(cfg, sd, self.device)
@@ -378,13 +378,13 @@ class XRestormer(Tool):
         super().__init__(tool_name="xrestormer", subtask=subtask, work_dir="X-Restormer", script_rel_path=Path("xrestormer") / 'inference.py')
         sub = canonical_subtask(subtask)
         if sub not in XRESTORMER_OPTS:
-            raise KeyError(f"X-Restormer on the HIP backend handles {sorted(XRESTORMER_OPTS)} (super_resolution needs scale 4), not {subtask!r}")
-        self.model_name, self.padding_size = XRESTORMER_OPTS[sub]
+            raise KeyError(f"X-Restormer handles {sorted(XRESTORMER_OPTS)}, not {subtask!r}")
+        self.model_name, self.padding_size, self.scale = XRESTORMER_OPTS[sub]
         self._cache = cache
         self.tile_size, self.tile_pad = tile_size, tile_pad
 
     def _invoke(self, *args) -> None:
-        be = (self._cache or default_xrestormer_cache()).get(self.model_name)
+        be = (self._cache or default_xrestormer_cache()).get(self.model_name, self.scale)
         src = sorted(Path(self.input_dir).glob('*'))[0]
         out = be.restore_padcrop(read_image(src, gray=False), tile_size=self.tile_size, tile_pad=self.tile_pad, padding_size=self.padding_size)
         write_png(Path(self.output_dir) / 'output.png', out)
@@ -452,14 +452,15 @@ def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[
     for key, sub in (('denoising', 'denoising'), ('motion deblurring', 'motion_deblurring'), ('deraining', 'deraining')):
         ex.toolbox_router[key] = [XRestormer(sub, xrestormer_cache)] + ex.toolbox_router[key]      # first in every reference toolbox it is in
     ex.register_subtask('dehazing', [XRestormer('dehazing', xrestormer_cache)])
-    ex.register_subtask('super-resolution', [SwinIR('super_resolution', 'gan', swinir_cache), SwinIR('super_resolution', 'psnr', swinir_cache)])
+    ex.register_subtask('super-resolution', [XRestormer('super_resolution', xrestormer_cache), SwinIR('super_resolution', 'gan', swinir_cache),
+                                             SwinIR('super_resolution', 'psnr', swinir_cache)])
     ex.register_subtask('jpeg compression artifact removal', [SwinIR('jpeg_compression_artifact_removal', '40', swinir_cache)])
     return ex
 
 
 def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
                  xrestormer_cache: Optional[XRestormerCache] = None) -> int:
-    """Drop-in: replace every tool named 'restormer', 'swinir_*' or 'xrestormer' (except the scale-4 SR one) in an existing
+    """Drop-in: replace every tool named 'restormer', 'swinir_*' or 'xrestormer' in an existing
     (reference) executor's toolboxes by the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.
     Returns the count."""
     n = 0

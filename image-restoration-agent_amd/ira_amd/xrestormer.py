@@ -3,7 +3,7 @@ AgenticIR/executor/dehazing/tools/X-Restormer/xrestormer/archs/xrestormer_arch.p
 AgentApp/model_service/dehazing/X-Restormer/X-Restormer/options/test/00{2,3,4,5}_xrestormer_*.yml).
 
 X-Restormer = the Restormer U-Net whose blocks are [channel attention (MDTA) + GDFN, overlapping cross-attention (OCAB) +
-GDFN] (:239-262).  scale > 1 (the SR preset: bilinear x4 of the input first, :378-379) is not built."""
+GDFN] (:239-262).  scale > 1 (the SR preset): the input is upsampled bilinearly first (:378-379) and the network runs at the output size."""
 from __future__ import annotations
 
 import zlib
@@ -153,8 +153,8 @@ def restormer_equivalent(cfg: XRestormerConfig):
 def xrestormer_cfg_struct(cfg: XRestormerConfig):
     from ._capi import IraXrestormerConfig
     from .backend import _cfg_struct
-    if cfg.scale != 1:
-        raise ValueError("scale > 1 (the SR preset's bilinear pre-upsampling) is not built")
+    if cfg.scale not in (1, 2, 4):
+        raise ValueError("scale must be 1, 2 or 4")
     s = IraXrestormerConfig()
     s.base = _cfg_struct(restormer_equivalent(cfg))
     for l in range(4):

@@ -85,8 +85,10 @@ def block(x, sd, p, cfg, lvl):
 
 
 def xrestormer_forward(inp, sd, cfg):
-    """XRestormer.forward (:376-410), scale 1.  H, W multiples of 8 * window_size (the harness pads to 64)."""
+    """XRestormer.forward (:376-410).  H*scale, W*scale multiples of 8 * window_size (the harness pads: padding_size 64, or 16 at scale 4)."""
     nb = cfg['num_blocks']
+    if cfg.get('scale', 1) > 1:
+        inp = F.interpolate(inp, scale_factor=cfg['scale'], mode='bilinear', align_corners=False)      # :378-379
 
     def stage(x, name, n, lvl):
         for i in range(n):

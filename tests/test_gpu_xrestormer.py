@@ -76,10 +76,29 @@ def test_forward_matches_reference_golden(path):
     y, ref = be.forward(z['input']), z['output']
     assert y.shape == ref.shape and np.isfinite(y).all()
     p = O.psnr_f(y, ref)
-    d = abs(O.psnr_u8(_u8(y), _u8(z['input'])) - O.psnr_u8(_u8(ref), _u8(z['input'])))
+    x = z['input']
+    if cfg.scale > 1:
+        x = np.repeat(np.repeat(x, cfg.scale, 2), cfg.scale, 3)
+    d = abs(O.psnr_u8(_u8(y), _u8(x)) - O.psnr_u8(_u8(ref), _u8(x)))
     print(f"{os.path.basename(path)}: PSNR(build, reference) {p:.2f} dB, max abs err {np.abs(y - ref).max():.3e}, |dPSNR_u8| {d:.2e}")
     assert p >= 58.0, p
     assert d <= 1e-3, d
+
+
+def test_sr_preset_padcrop_harness():
+    """executor/super_resolution/configs/xrestormer.yml: scale 4, padding_size 16, untiled; and a tiled run."""
+    cfg = reduced_xrestormer_config(scale=4)
+    be = backend(cfg, 4)
+    sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 4).items()}
+    _, img = synthetic_noisy_image(27, 40, 3, sigma=10.0, seed=6)
+    fwd = lambda t: X.xrestormer_forward(t, sd, cfg.to_dict())
+    for ts, tp in ((None, 32), (16, 16)):
+        got = be.restore_padcrop(img, tile_size=ts, tile_pad=tp, padding_size=16)
+        ref = padcrop_restore_image(img, fwd, ts, tp, 16, scale=4)
+        assert got.shape == ref.shape == (108, 160, 3)
+        diff = np.abs(got.astype(int) - ref.astype(int))
+        print(f"sr x4 tile={ts}: {100 * (diff > 0).mean():.2f}% px differ, max {diff.max()} LSB")
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.05
 
 
 def test_padcrop_harness_and_errors():

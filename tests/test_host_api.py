@@ -73,7 +73,7 @@ def test_executor_registry_and_directory_protocol(tmp_path, cache):
     assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['xrestormer', 'swinir_15', 'swinir_50', 'restormer']     # reference order
     assert [t.tool_name for t in ex.toolbox_router['motion deblurring']] == ['xrestormer', 'restormer']
     assert [t.tool_name for t in ex.toolbox_router['dehazing']] == ['xrestormer']
-    assert [t.tool_name for t in ex.toolbox_router['super-resolution']] == ['swinir_gan', 'swinir_psnr']
+    assert [t.tool_name for t in ex.toolbox_router['super-resolution']] == ['xrestormer', 'swinir_gan', 'swinir_psnr']
     assert [t.tool_name for t in ex.toolbox_router['jpeg compression artifact removal']] == ['swinir_40']
     root = tmp_path / 'task'
     (root / '0-img').mkdir(parents=True)
@@ -98,9 +98,9 @@ def test_install_into_reference_executor(cache):
         toolbox_router['super-resolution'] = [RefTool('diffbir', 'super_resolution'), RefTool('swinir_gan', 'super_resolution'),
                                               RefTool('xrestormer', 'super_resolution')]
     n = T.install_into(RefExecutor, cache)
-    assert n == 3          # restormer, swinir_gan, xrestormer(denoising); the scale-4 xrestormer of super-resolution stays
+    assert n == 4          # restormer, swinir_gan, xrestormer (denoising), xrestormer (super-resolution, scale 4)
     assert isinstance(RefExecutor.toolbox_router['denoising'][0], T.XRestormer)
-    assert not isinstance(RefExecutor.toolbox_router['super-resolution'][2], T.XRestormer)
+    assert RefExecutor.toolbox_router['super-resolution'][2].scale == 4
     tb = RefExecutor.toolbox_router['denoising']
     assert tb[0].tool_name == 'xrestormer' and isinstance(tb[1], T.Restormer) and tb[1].opt_task == 'Real_Denoising'
     sr = RefExecutor.toolbox_router['super-resolution']
@@ -274,7 +274,9 @@ def test_xrestormer_tool_contract(tmp_path):
     tool(inp, out, silent=True)
     assert os.listdir(out) == ['output.png'] and np.array_equal(np.asarray(Image.open(out / 'output.png')), 255 - img)
     assert calls == [((21, 30, 3), None, 32, 64)]
-    assert xc.get('dehaze_300k.pth').cfg.spatial_heads == [1, 2, 4, 8] and xc.get('dehaze_300k.pth').sd == 'dehaze_300k.pth'
+    assert xc.get('dehaze_300k.pth').cfg.scale == 1 and xc.get('dehaze_300k.pth').cfg.spatial_heads == [1, 2, 4, 8] and xc.get('dehaze_300k.pth').sd == 'dehaze_300k.pth'
     assert T.XRestormer('deraining', cache=xc).model_name == 'derain_155k.pth'
+    sr = T.XRestormer('super_resolution', cache=xc)
+    assert (sr.model_name, sr.padding_size, sr.scale) == ('sr_300k.pth', 16, 4)
     with pytest.raises(KeyError):
-        T.XRestormer('super_resolution', cache=xc)
+        T.XRestormer('brightening', cache=xc)
