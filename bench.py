@@ -441,9 +441,92 @@ def main_xrestormer(args):
         dist.destroy_process_group()
 
 
+def main_agent_chain(args):
+    """BASELINE configs[4] without the LLM: a FIXED plan {denoising -> motion deblurring -> super-resolution} executed through the
+    agent-facing registry (ira_amd.tools.Executor.execute_subtask: directory protocol, PNG in / PNG out per tool, exactly what
+    AgentApp/agentic_api.py:188-196 drives), one 960x540 frame -> 3840x2160.  Tools: restormer, restormer, swinir_psnr (seeded weights).
+    One step = the whole chain on one frame incl. PNG decode/encode and host<->device copies; N > 1: independent replicas."""
+    import shutil
+    import tempfile
+    from pathlib import Path
+    import numpy as np
+    import torch
+    from PIL import Image
+    from ira_amd import tools as T
+    from ira_amd.synth import synthetic_noisy_image
+    from ira_amd.swinir import seeded_state_dict as sw_seeded, task_config as sw_task
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cache = T.BackendCache(device=local_rank, state_dict_loader=T.seeded_state_dict_loader(0))
+    swc = T.SwinIRCache(device=local_rank, state_dict_loader=lambda task, name, wd: sw_seeded(sw_task(task, 4, True), 0))
+    ex = T.Executor()
+    ex.register_subtask('denoising', [T.Restormer('denoising', cache=cache)])
+    ex.register_subtask('motion deblurring', [T.Restormer('motion_deblurring', cache=cache)])
+    ex.register_subtask('super-resolution', [T.SwinIR('super_resolution', 'psnr', cache=swc)])
+    plan = ['denoising', 'motion deblurring', 'super-resolution']
+    h, w = 540, 960
+    _, noisy = synthetic_noisy_image(h, w, 3, sigma=15.0, seed=rank)
+    root = Path(tempfile.mkdtemp(prefix=f'ira_chain_{rank}_'))
+
+    def one_frame(i):
+        d = root / f'f{i}' / '0-img'
+        d.mkdir(parents=True)
+        Image.fromarray(noisy).save(d / 'input.png')
+        path = d / 'input.png'
+        ex._executed_subtask_cnt = 0
+        for sub in plan:
+            path = ex.execute_subtask(sub, path)                 # executor/__init__.py:40-85
+        return path
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):              # the tools print like the reference's (tool.py:35-49)
+        for i in range(args.warmup):
+            one_frame(f'w{i}')
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = one_frame(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    out_shape = np.asarray(Image.open(last)).shape
+    shutil.rmtree(root, ignore_errors=True)
+    cache.close(); swc.close()
+    if rank == 0:
+        step_s = elapsed / args.steps
+        print(json.dumps({
+            'metric': 'agent tool chain frames/sec (denoise -> deblur -> x4 SR through the tool registry, 960x540 -> 3840x2160, PNG in/out)',
+            'value': round(world / step_s, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * step_s, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16 storage / f32 accumulate', 'data': 'synthetic',
+            'config': {'workload': 'fixed plan [denoising:restormer, motion deblurring:restormer, super-resolution:swinir_psnr] via '
+                                   'ira_amd.tools.Executor.execute_subtask (directory protocol, PIL PNG decode/encode, host buffers), '
+                                   f'seeded weights, output {out_shape[1]}x{out_shape[0]}', 'output_MP_per_s': round(world * out_shape[0] * out_shape[1] / 1e6 / step_s, 3)},
+            'roofline': {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+                         'note': 'end-to-end line incl. PNG codec and PCIe: see the per-network workloads for kernel rooflines'}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4', 'xrestormer720p'],
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4', 'xrestormer720p', 'agent_chain'],
                     help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = configs[1]; swinir_x4 = configs[3]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -463,6 +546,8 @@ def main():
         return main_swinir(args)
     if args.workload == 'xrestormer720p':
         return main_xrestormer(args)
+    if args.workload == 'agent_chain':
+        return main_agent_chain(args)
 
     import numpy as np
     import torch

@@ -170,13 +170,53 @@ def read_image(path, gray: bool = False) -> np.ndarray:
         return np.asarray(im.convert('RGB'), dtype=np.uint8).copy()
 
 
-def write_png(path, img: np.ndarray):
-    """demo.py:43-50 (cv2.imwrite PNG): lossless, so the decoder/encoder library does not matter."""
-    from PIL import Image
-    a = np.asarray(img)
+def encode_png(img: np.ndarray, level: int = 1) -> bytes:
+    """Lossless 8-bit PNG (gray or RGB) with filter type 0 on every row and one zlib stream.  PIL's / libpng's adaptive row
+    filtering costs 1.4 s for a 3840x2160 frame whatever the zlib level; this is 0.15 s, and any PNG reader decodes it."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(img)
     if a.ndim == 3 and a.shape[2] == 1:
         a = a[:, :, 0]
-    Image.fromarray(a).save(path, format='PNG')
+    if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError("encode_png expects uint8 (h,w), (h,w,1) or (h,w,3)")
+    h, w = a.shape[:2]
+    rows = np.zeros((h, 1 + (w * (3 if a.ndim == 3 else 1))), np.uint8)
+    rows[:, 1:] = a.reshape(h, -1)
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xFFFFFFFF)
+    ihdr = struct.pack('>IIBBBBB', w, h, 8, 2 if a.ndim == 3 else 0, 0, 0, 0)
+    return b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', ihdr) + chunk(b'IDAT', _deflate_parallel(rows.tobytes(), level)) + chunk(b'IEND', b'')
+
+
+def _deflate_parallel(raw: bytes, level: int, stripe: int = 1 << 20) -> bytes:
+    """One valid zlib stream built from independently deflated 1 MB stripes (pigz's scheme: every stripe but the last ends with a
+    sync flush, so the raw deflate blocks concatenate; the Adler-32 trailer is computed over the whole input).  zlib releases
+    the GIL, so the stripes run on a thread pool: 25 MB in ~0.1 s instead of 0.75 s."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    n = max(1, (len(raw) + stripe - 1) // stripe)
+    if level > 0 and len(raw) > (1 << 20):
+        mid = len(raw) // 2
+        probe = raw[mid:mid + (1 << 18)]
+        if len(zlib.compress(probe, 1)) > 0.9 * len(probe):
+            level = 0                                  # noise-like content does not deflate: store it (40 ms instead of 0.8 s for a 4K frame)
+
+    def work(i):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        data = co.compress(raw[i * stripe:(i + 1) * stripe])
+        return data + (co.flush(zlib.Z_FINISH) if i == n - 1 else co.flush(zlib.Z_SYNC_FLUSH))
+    with ThreadPoolExecutor(max_workers=min(16, n)) as ex:
+        parts = list(ex.map(work, range(n)))
+    return b'\x78\x01' + b''.join(parts) + struct.pack('>I', zlib.adler32(raw) & 0xFFFFFFFF)
+
+
+def write_png(path, img: np.ndarray):
+    """demo.py:43-50 (cv2.imwrite PNG): lossless, so the encoder does not matter to the pixels."""
+    with open(path, 'wb') as f:
+        f.write(encode_png(img))
 
 
 class Restormer(Tool):
