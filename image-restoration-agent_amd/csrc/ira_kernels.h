@@ -103,4 +103,14 @@ hipError_t launch_lrelu(hipStream_t st, float* x, long n, float slope);
 hipError_t launch_bilinear_up(hipStream_t st, const float* in, float* out, int T, int H, int W, int C, int s);
 hipError_t launch_ocab_attn(hipStream_t st, const void* qkv, const float* rel, void* out, int T, int H, int W, int heads);
 
+// ---- MPRNet (ira_mprnet.hip): fp32 NHWC, channels padded to a multiple of 16
+int mpr_ca_blocks(long P);          // partial records per image used by launch_mpr_ca
+hipError_t launch_mpr_ca(hipStream_t st, const float* x, float* part, const float* w1, const float* w2, float* z, int T, long P, int C, int Cp, int Cr);
+hipError_t launch_mpr_scale_add(hipStream_t st, const float* res, const float* z, const float* x, float* out, int T, long P, int Cp);
+hipError_t launch_mpr_sam(hipStream_t st, const float* x1, const float* y8, const float* ximg, const float* w3, const float* x, float* out,
+                          float* img_out, int C, int Cp, long npx);
+// wide [N][h][2w][C] <-> halves [2N][h][w][C] (half image 2n + lr); merge 0: split, 1: concatenate
+hipError_t launch_mpr_lr(hipStream_t st, float* wide, float* halves, int N, int h, int w, int C, int merge);
+hipError_t launch_mpr_up2(hipStream_t st, const float* in, const float* add, float* out, int T, int H, int W, int C);
+
 }  // namespace ira

@@ -61,7 +61,7 @@ using ira_rt::Blk; using ira_rt::Prof; using ira_rt::SBlk; using ira_rt::SConv; 
 
 struct ira_model {
     int device = -1;
-    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR
+    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR, 4 MPRNet
     ira_restormer_config cfg{};
     bool xr = false;                 // arch 0 with X-Restormer blocks
     int xr_spatial_heads[4] = {0, 0, 0, 0};
@@ -70,6 +70,7 @@ struct ira_model {
     ira_nafnet_config ncfg{};
     ira_dncnn_config dcfg{};
     ira_swinir_config scfg{};
+    ira_mprnet_config mcfg{};
     std::vector<std::vector<SBlk>> sw_blocks;
     std::vector<SConv> sw_lconv;
     SConv sw_cab;
@@ -201,5 +202,7 @@ bool dn_bind_weights(ira_model* m);
 int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool sw_bind_weights(ira_model* m);
 int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
+bool mpr_bind_weights(ira_model* m);
+int mpr_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 
 }  // namespace ira_rt

@@ -21,7 +21,7 @@ namespace ira {
 namespace {
 
 
-enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3, IN_SCALED = 4 };
+enum { IN_F16 = 0, IN_GATED = 1, IN_S2D = 2, IN_F32 = 3, IN_SCALED = 4, IN_F32X2 = 5, IN_S2DX2 = 6 };
 enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
 
 }  // namespace
@@ -36,6 +36,8 @@ enum { OUT_RES = 0, OUT_SHUFFLE_ADD = 1 };
 //   IN_F32    x: fp32 [T][P][K]
 //   IN_SCALED x: fp16 [T][P][K], B = x[.., k] * scale[t][k]   (the channel attention x * sca(x), :205, without building a
 //             per-image matrix)
+//   IN_F32X2 / IN_S2DX2: as IN_F32 / IN_S2D with the fp32 pixel operand split into fp16 hi + lo (third MFMA per block): the
+//             1x1 convolutions of MPRNet's fp32 feature streams
 //   OUT_RES          y fp32 [T][P][N] = acc (+ resid)
 //   OUT_SHUFFLE_ADD  y fp32 [T][2Hg][2Wg][N/4]: row n = q*(N/4) + cc -> sub-pixel q = 2sy+sx, channel cc; + resid there
 template <int NBW, int INMODE, int OUTMODE>
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, in
         }
         const int c0 = 16 * s + 8 * h;
         half8 b;
+        [[maybe_unused]] half8 bl;
         if constexpr (INMODE == IN_F16) {
             b = *(const half8*)((const f16*)xin + px * K + c0);
         } else if constexpr (INMODE == IN_SCALED) {
@@ -111,18 +114,27 @@ __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, in
             const half8 a1 = *(const half8*)src, a2 = *(const half8*)(src + K);
 #pragma unroll
             for (int j = 0; j < 8; ++j) b[j] = (f16)((float)a1[j] * (float)a2[j]);
-        } else if constexpr (INMODE == IN_S2D) {
-            const int tap = s / spt, ci0 = (s - tap * spt) * 16 + 8 * h;
-            const float* src = (const float*)xin + (((long)t * 2 * Hg + 2 * Y + (tap >> 1)) * (2 * Wg) + 2 * X + (tap & 1)) * cs + ci0;
-            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
         } else {
-            const float* src = (const float*)xin + px * K + c0;
-            b = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+            const float* src;
+            if constexpr (INMODE == IN_S2D || INMODE == IN_S2DX2) {
+                const int tap = s / spt, ci0 = (s - tap * spt) * 16 + 8 * h;
+                src = (const float*)xin + (((long)t * 2 * Hg + 2 * Y + (tap >> 1)) * (2 * Wg) + 2 * X + (tap & 1)) * cs + ci0;
+            } else {
+                src = (const float*)xin + px * K + c0;
+            }
+            const f32x4 lo4 = *(const f32x4*)src, hi4 = *(const f32x4*)(src + 4);
+            b = cvt8(lo4, hi4);
+            if constexpr (INMODE == IN_F32X2 || INMODE == IN_S2DX2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bl[j] = (f16)(lo4[j] - (float)b[j]); bl[4 + j] = (f16)(hi4[j] - (float)b[4 + j]); }
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[nb * 64 + lane], b, acc[nb], 0, 0, 0);
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(NBW + nb) * 64 + lane], b, acc[nb], 0, 0, 0);
+            if constexpr (INMODE == IN_F32X2 || INMODE == IN_S2DX2)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[nb * 64 + lane], bl, acc[nb], 0, 0, 0);
         }
         if (s + 1 < KT) {
             half8* nxt = wl + ((s + 1) & 1) * F * 64;
@@ -479,7 +491,7 @@ hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x,
                          const float* scale) {
     if (inmode == IN_SCALED && scale == nullptr) return hipErrorInvalidValue;
     if (K <= 0 || K % 16 != 0 || N % 8 != 0 || NBtot * 32 < N || T <= 0 || Hg <= 0 || Wg <= 0) return hipErrorInvalidValue;
-    if (inmode == IN_S2D && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
+    if ((inmode == IN_S2D || inmode == IN_S2DX2) && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
     if (outmode == OUT_SHUFFLE_ADD && (N % 32 != 0)) return hipErrorInvalidValue;  // N/4 channels, runs of 8
     const f16* Wh = (const f16*)W;
 #define IRA_NAF(IM, OM) return naf_pw_nbw<IM, OM>(st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, Hg, Wg, scale)
@@ -490,6 +502,8 @@ hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x,
             case IN_S2D: IRA_NAF(IN_S2D, OUT_RES);
             case IN_F32: IRA_NAF(IN_F32, OUT_RES);
             case IN_SCALED: IRA_NAF(IN_SCALED, OUT_RES);
+            case IN_F32X2: IRA_NAF(IN_F32X2, OUT_RES);
+            case IN_S2DX2: IRA_NAF(IN_S2DX2, OUT_RES);
             default: return hipErrorInvalidValue;
         }
     } else if (outmode == OUT_SHUFFLE_ADD && inmode == IN_F32) {

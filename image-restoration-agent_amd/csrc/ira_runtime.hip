@@ -25,6 +25,7 @@ using namespace ira_rt;
 namespace {
 
 int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    if (m->arch == 4) return mpr_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 3) return sw_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 2) return dn_forward_enqueue(m, in, T, H, W, out);
     return m->arch == 1 ? naf_forward_enqueue(m, in, T, H, W, out) : restormer_forward_enqueue(m, in, T, H, W, out);
@@ -285,6 +286,30 @@ int ira_dncnn_create(int device, const ira_dncnn_config* cfg, const void* blob, 
     m->arch = 2; m->dcfg = *cfg;
     m->cfg.inp_channels = m->cfg.out_channels = cfg->in_nc;
     if (!dn_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
+    *out = m;
+    return IRA_OK;
+}
+
+int ira_mprnet_create(int device, const ira_mprnet_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_mprnet_create: NULL argument");
+    *out = nullptr;
+    if (cfg->in_c != 3 || cfg->out_c != 3) return gfail(IRA_ERR_ARG, "in_c / out_c must be 3 (SAM adds the 3-channel stage image), got %d / %d", cfg->in_c, cfg->out_c);
+    if (cfg->n_feat < 4 || cfg->scale_unetfeats < 0 || cfg->scale_orsnetfeats < 0 || cfg->n_feat + 2 * cfg->scale_unetfeats > 256 ||
+        cfg->n_feat + cfg->scale_orsnetfeats > 256)
+        return gfail(IRA_ERR_ARG, "n_feat=%d scale_unetfeats=%d scale_orsnetfeats=%d: widths must stay within 4..256 channels", cfg->n_feat,
+                     cfg->scale_unetfeats, cfg->scale_orsnetfeats);
+    if (cfg->num_cab < 1) return gfail(IRA_ERR_ARG, "num_cab must be >= 1, got %d", cfg->num_cab);
+    if (cfg->reduction < 1 || cfg->n_feat / cfg->reduction < 1) return gfail(IRA_ERR_ARG, "reduction=%d leaves no channel in the attention bottleneck", cfg->reduction);
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 4; m->mcfg = *cfg;
+    m->cfg.inp_channels = m->cfg.out_channels = 3;
+    if (!mpr_bind_weights(m)) {
         g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
         ira_model_destroy(m);
         return IRA_ERR_WEIGHTS;

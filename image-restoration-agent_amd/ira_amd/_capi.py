@@ -56,6 +56,11 @@ class IraDncnnConfig(C.Structure):
     _fields_ = [('in_nc', C.c_int32), ('nc', C.c_int32), ('nb', C.c_int32)]
 
 
+class IraMprnetConfig(C.Structure):
+    _fields_ = [('in_c', C.c_int32), ('out_c', C.c_int32), ('n_feat', C.c_int32), ('scale_unetfeats', C.c_int32),
+                ('scale_orsnetfeats', C.c_int32), ('num_cab', C.c_int32), ('reduction', C.c_int32), ('prelu', C.c_float)]
+
+
 _vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 _pi = C.POINTER(C.c_int)
 
@@ -67,6 +72,7 @@ SIGNATURES = {
     'ira_nafnet_create': (_i, [_i, C.POINTER(IraNafnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_dncnn_create': (_i, [_i, C.POINTER(IraDncnnConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_swinir_create': (_i, [_i, C.POINTER(IraSwinirConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_mprnet_create': (_i, [_i, C.POINTER(IraMprnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_model_destroy': (_i, [_vp]),
     'ira_last_error': (C.c_char_p, [_vp]),
     'ira_sync': (_i, [_vp]),

@@ -201,6 +201,17 @@ class DnCNNBackend(_Backend):
         self._create(device, 'ira_dncnn_create', dncnn_cfg_struct(cfg), pack_dncnn_blob(state_dict, cfg), 'ira_dncnn_create')
 
 
+class MPRNetBackend(_Backend):
+    """One MPRNet on one MI355X (AgenticIR/executor/denoising/tools/MPRNet).  ``forward``: float32 (B,3,H,W), H and W
+    multiples of 8, -> the stage-3 image (restored[0] of the reference's list).  ``restore(img, tile=None)``: the demo.py:64-87 harness."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .mprnet import pack_mprnet_blob, mprnet_cfg_struct, prelu_value
+        self.cfg = cfg
+        self._create(device, 'ira_mprnet_create', mprnet_cfg_struct(cfg, prelu_value(state_dict)), pack_mprnet_blob(state_dict, cfg),
+                     'ira_mprnet_create')
+
+
 class SwinIRBackend(_Backend):
     """One SwinIR on one MI355X (SwinIR/models/network_swinir.py).  ``forward``: float32 (B,C,H,W) ->
     (B,C,H*upscale,W*upscale), any H, W.  ``restore``: the reference harness (SwinIR/inference.py:69-90,294-322: always-pad by

@@ -121,3 +121,98 @@ def seeded_state_dict(cfg: MPRNetConfig, seed: int = 0):
     for n, s in state_dict_spec(cfg):
         out[n] = np.full(s, prelu, np.float32) if n.endswith('.body.1.weight') else seeded_tensor(seed, n, s)
     return out
+
+
+def up16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def prelu_value(sd) -> float:
+    """The one shared PReLU parameter; a state dict whose '...body.1.weight' entries disagree was not produced by the reference module."""
+    vals = {float(np.asarray(v).reshape(-1)[0]) for k, v in sd.items() if k.endswith('.body.1.weight')}
+    if len(vals) != 1:
+        raise ValueError(f"expected one shared PReLU value, found {sorted(vals)[:4]}")
+    return vals.pop()
+
+
+def mprnet_cfg_struct(cfg: MPRNetConfig, prelu: float):
+    from ._capi import IraMprnetConfig
+    return IraMprnetConfig(cfg.in_c, cfg.out_c, cfg.n_feat, cfg.scale_unetfeats, cfg.scale_orsnetfeats, cfg.num_cab, cfg.reduction, prelu)
+
+
+def pack_mprnet_arrays(sd, cfg: MPRNetConfig) -> dict:
+    """Blob entries of csrc/ira_rt_mprnet.hip.  Channels are zero-padded to multiples of 16; DownSample = 2x2 mean + 1x1 becomes one
+    [(dy,dx,ci)] contraction with W/4 per tap; the ORSNet up -> 1x1 chains (MPRNet.py:229-231) are multiplied out in float64."""
+    from .pack import frag_major, split16, up32, _np
+    from .swinir import _conv3_pack_k
+    f64 = lambda k: _np(sd[k]).astype(np.float64)
+    m2 = lambda k: f64(k)[:, :, 0, 0]
+    out: dict = {}
+
+    def pw(w):                                             # [cout][cin] -> hi/lo fragment-major, rows up32(up16(cout)), K up16(cin)
+        co, ci = w.shape
+        a = np.zeros((up32(up16(co)), up16(ci)), np.float64)
+        a[:co, :ci] = w
+        return frag_major(split16(a))
+
+    def cab(p, c):
+        cp = up16(c)
+        out[f'{p}.c0'] = _conv3_pack_k(f64(f'{p}.body.0.weight'), cp)
+        out[f'{p}.c2'] = _conv3_pack_k(f64(f'{p}.body.2.weight'), cp)
+        out[f'{p}.du0'] = np.ascontiguousarray(_np(sd[f'{p}.CA.conv_du.0.weight'])[:, :, 0, 0])
+        out[f'{p}.du2'] = np.ascontiguousarray(_np(sd[f'{p}.CA.conv_du.2.weight'])[:, :, 0, 0])
+
+    n, su, so = cfg.n_feat, cfg.scale_unetfeats, cfg.scale_orsnetfeats
+    ch, co = (n, n + su, n + 2 * su), n + so
+    np_ = up16(n)
+    for i in (1, 2, 3):
+        w = np.zeros((np_, cfg.in_c, 3, 3), np.float32)
+        w[:n] = _np(sd[f'shallow_feat{i}.0.weight'])
+        out[f'shallow_feat{i}.0'] = w
+        cab(f'shallow_feat{i}.1', n)
+    for s in (1, 2):
+        e, d = f'stage{s}_encoder', f'stage{s}_decoder'
+        for lvl in (1, 2, 3):
+            for k in range(2):
+                cab(f'{e}.encoder_level{lvl}.{k}', ch[lvl - 1])
+                cab(f'{d}.decoder_level{lvl}.{k}', ch[lvl - 1])
+        for lvl in (1, 2):
+            w = m2(f'{e}.down{lvl}{lvl + 1}.down.1.weight')                        # [c_next][c]
+            cn, c = w.shape
+            a = np.zeros((up32(up16(cn)), 4, up16(c)), np.float64)
+            a[:cn, :, :c] = (w / 4.0)[:, None, :]
+            out[f'{e}.down{lvl}{lvl + 1}'] = frag_major(split16(a.reshape(a.shape[0], -1)))
+            cab(f'{d}.skip_attn{lvl}', ch[lvl - 1])
+            out[f'{d}.up{lvl + 1}{lvl}'] = pw(m2(f'{d}.up{lvl + 1}{lvl}.up.1.weight'))
+        if s == 2:
+            for kind in ('enc', 'dec'):
+                for lvl in (1, 2, 3):
+                    out[f'{e}.csff_{kind}{lvl}'] = pw(m2(f'{e}.csff_{kind}{lvl}.weight'))
+    o = 'stage3_orsnet'
+    for i in (1, 2, 3):
+        for k in range(cfg.num_cab):
+            cab(f'{o}.orb{i}.body.{k}', co)
+        out[f'{o}.orb{i}.body.{cfg.num_cab}'] = _conv3_pack_k(f64(f'{o}.orb{i}.body.{cfg.num_cab}.weight'), up16(co))
+    for kind in ('enc', 'dec'):
+        out[f'{o}.{kind}1'] = pw(m2(f'{o}.conv_{kind}1.weight'))
+        out[f'{o}.{kind}2'] = pw(m2(f'{o}.conv_{kind}2.weight') @ m2(f'{o}.up_{kind}1.up.1.weight'))
+        out[f'{o}.{kind}3'] = pw(m2(f'{o}.conv_{kind}3.weight') @ m2(f'{o}.up_{kind}2.1.up.1.weight') @ m2(f'{o}.up_{kind}2.0.up.1.weight'))
+    for s in ('sam12', 'sam23'):
+        out[f'{s}.conv1'] = pw(m2(f'{s}.conv1.weight'))
+        a = np.zeros((32, np_), np.float64)
+        a[:3, :n] = m2(f'{s}.conv2.weight')
+        out[f'{s}.conv2'] = frag_major(split16(a))
+        out[f'{s}.conv3'] = np.ascontiguousarray(_np(sd[f'{s}.conv3.weight'])[:, :, 0, 0])
+    for name, cout in (('concat12', n), ('concat23', co)):
+        w = f64(f'{name}.weight')                                                  # [cout][2n][3][3]: [shallow | sam] (:305, :330)
+        a = np.zeros((cout, 2 * np_, 3, 3), np.float64)
+        a[:, :n] = w[:, :n]
+        a[:, np_:np_ + n] = w[:, n:]
+        out[name] = _conv3_pack_k(a, 2 * np_)
+    out['tail'] = _conv3_pack_k(f64('tail.weight'), up16(co))
+    return out
+
+
+def pack_mprnet_blob(sd, cfg: MPRNetConfig) -> bytes:
+    from .pack import blob_from_arrays
+    return blob_from_arrays(pack_mprnet_arrays(sd, cfg))

@@ -107,6 +107,17 @@ typedef struct ira_swinir_config {
     int32_t resi_3conv;                               /* 0 '1conv', 1 '3conv' */
 } ira_swinir_config;
 
+/* Constructor arguments of the reference MPRNet (AgenticIR/executor/denoising/tools/MPRNet/{Deblurring,Denoising,Deraining}/MPRNet.py:239:
+ * 96/48/32, 80/48/32, 40/20/16; kernel_size 3, bias False in all three).  `prelu` is the single parameter of the nn.PReLU() instance every
+ * CAB shares (:242). */
+typedef struct ira_mprnet_config {
+    int32_t in_c, out_c;                              /* 3, 3 */
+    int32_t n_feat, scale_unetfeats, scale_orsnetfeats;
+    int32_t num_cab;                                  /* 8 */
+    int32_t reduction;                                /* 4 */
+    float   prelu;
+} ira_mprnet_config;
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
@@ -135,6 +146,12 @@ int ira_dncnn_create(int device, const ira_dncnn_config* cfg,
 /* SwinIR: blob from ira_amd/swinir.py::pack_swinir_blob.  ira_forward(_device) then take (B, in_chans, H, W) of any size
  * (reflect-padded to the window inside, network_swinir.py:783-788) and return (B, in_chans, H*upscale, W*upscale). */
 int ira_swinir_create(int device, const ira_swinir_config* cfg,
+                      const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* MPRNet: blob from ira_amd/mprnet.py::pack_mprnet_blob.  ira_forward(_device) take (B, 3, H, W) with H, W multiples of 8 and return the
+ * stage-3 image, the tensor the reference harness keeps (restored = model(input_); restored[0], MPRNet/demo.py:79-80); the harness around
+ * it (pad to 8 by reflection, clamp, crop, img_as_ubyte, demo.py:70-87) is ira_restore_u8 with tile = 0.
+ * replaces: load_file("MPRNet.py").MPRNet(); utils.load_checkpoint; model.cuda().eval()  (MPRNet/demo.py:57-62). */
+int ira_mprnet_create(int device, const ira_mprnet_config* cfg,
                       const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
 int ira_model_destroy(ira_model_t* model);
 
