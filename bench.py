@@ -346,13 +346,10 @@ def main_swinir(args):
         dist.destroy_process_group()
 
 
-def main_xrestormer(args):
-    """X-Restormer (SURVEY 8 row f1; the agent's `xrestormer` tool runs whole images padded to a multiple of 64): one 1280x720 frame
-    = (1, 768, 1280, 3) float32 NHWC resident in HBM through the network, output in HBM.  N > 1: independent replicas."""
-    import numpy as np
+def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_forward, cpu_name, crop=128):
+    """One (1, H, W, 3) float32 NHWC frame resident in HBM through a whole-image network, output in HBM.  N > 1: independent replicas.
+    make_backend(local_rank) -> backend; cpu_forward(x_nchw_cpu) = the oracle forward (cpu_baseline leg only)."""
     import torch
-    from ira_amd.backend import XRestormerBackend
-    from ira_amd.xrestormer import XRestormerConfig, seeded_state_dict
     from ira_amd.synth import synthetic_noisy_image
 
     rank = int(os.environ.get('RANK', '0'))
@@ -364,9 +361,7 @@ def main_xrestormer(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    cfg = XRestormerConfig()
-    be = XRestormerBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
-    H, W = 768, 1280
+    be = make_backend(local_rank)
     _, noisy = synthetic_noisy_image(H, W, 3, sigma=25.0, seed=rank)
     x = torch.from_numpy(noisy).float().div(255.).unsqueeze(0).contiguous().to(dev)
     y = torch.empty_like(x)
@@ -395,12 +390,9 @@ def main_xrestormer(args):
             dist.destroy_process_group()
         return
     step_s = elapsed / args.steps
-    result = {'metric': 'restored megapixels/sec (X-Restormer, 1280x720 frame padded to 768 rows, whole image)',
-              'value': round(world * H * W / 1e6 / step_s, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-              'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-              'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic',
-              'config': {'workload': 'X-Restormer dim 48, blocks [2,4,4,4]+4, channel/spatial heads [1,2,4,8] (26.0M params, seeded weights), '
-                                     f'(1, {H}, {W}, 3) float32 per GPU per step'}}
+    result = {'metric': metric, 'value': round(world * H * W / 1e6 / step_s, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps,
+              'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+              'dtype': dtype, 'data': 'synthetic', 'config': {'workload': workload + f', (1, {H}, {W}, 3) float32 per GPU per step'}}
     if world == 1 and not args.no_kernel_profile:
         be.profile_enable(True)
         be.forward_device(x.data_ptr(), 1, H, W, y.data_ptr())
@@ -421,24 +413,62 @@ def main_xrestormer(args):
     else:
         result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
     if world == 1 and not args.no_cpu_baseline:
-        from oracle.xrestormer_oracle import xrestormer_forward
         cores = min(16, os.cpu_count() or 1)
         torch.set_num_threads(cores)
-        sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
-        xc = x[:, :128, :128].cpu().permute(0, 3, 1, 2).contiguous()
+        xc = x[:, :crop, :crop].cpu().permute(0, 3, 1, 2).contiguous()
         with torch.no_grad():
-            xrestormer_forward(xc, sd, cfg.to_dict())
+            cpu_forward(xc)
             t1 = time.perf_counter()
             reps = 2
             for _ in range(reps):
-                xrestormer_forward(xc, sd, cfg.to_dict())
+                cpu_forward(xc)
             dt = (time.perf_counter() - t1) / reps
-        result['cpu_baseline'] = {'value': round(128 * 128 / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
-                                  'sample': f'oracle/xrestormer_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one 128x128 crop after 1 warm-up ({dt:.2f} s each)'}
+        result['cpu_baseline'] = {'value': round(crop * crop / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+                                  'sample': f'{cpu_name} (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {crop}x{crop} crop after 1 warm-up ({dt:.2f} s each)'}
     print(json.dumps(result), flush=True)
     be.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_xrestormer(args):
+    """X-Restormer (SURVEY 8 row f1; the agent's `xrestormer` tool runs whole images padded to a multiple of 64): one 1280x720 frame
+    = (1, 768, 1280, 3)."""
+    import torch
+    from ira_amd.backend import XRestormerBackend
+    from ira_amd.xrestormer import XRestormerConfig, seeded_state_dict
+    cfg = XRestormerConfig()
+
+    def cpu_forward(xc):
+        from oracle.xrestormer_oracle import xrestormer_forward
+        if not hasattr(cpu_forward, 'sd'):
+            cpu_forward.sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        return xrestormer_forward(xc, cpu_forward.sd, cfg.to_dict())
+    return _whole_image_bench(
+        args, lambda lr: XRestormerBackend(cfg, seeded_state_dict(cfg, 0), device=lr), 768, 1280,
+        'restored megapixels/sec (X-Restormer, 1280x720 frame padded to 768 rows, whole image)',
+        'X-Restormer dim 48, blocks [2,4,4,4]+4, channel/spatial heads [1,2,4,8] (26.0M params, seeded weights)',
+        'f16 storage / f32 accumulate + f32 residual stream', cpu_forward, 'oracle/xrestormer_oracle.py')
+
+
+def main_mprnet(args):
+    """MPRNet (the agent's `mprnet` tool runs every image whole, demo.py:64-87): one 1280x720 frame through the
+    motion-deblurring network (n_feat 96, scale_unetfeats 48, scale_orsnetfeats 32)."""
+    import torch
+    from ira_amd.backend import MPRNetBackend
+    from ira_amd.mprnet import seeded_state_dict, task_config
+    cfg = task_config('Deblurring')
+
+    def cpu_forward(xc):
+        from oracle.mprnet_oracle import mprnet_forward
+        if not hasattr(cpu_forward, 'sd'):
+            cpu_forward.sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        return mprnet_forward(xc, cpu_forward.sd, cfg.to_dict())
+    return _whole_image_bench(
+        args, lambda lr: MPRNetBackend(cfg, seeded_state_dict(cfg, 0), device=lr), 720, 1280,
+        'restored megapixels/sec (MPRNet motion deblurring, 1280x720 frame, whole image)',
+        'MPRNet Deblurring n_feat 96 / 48 / 32, 8 CABs per ORB (20.1M params, seeded weights)',
+        'f32 streams, f16 hi+lo MFMA operands, f32 accumulate', cpu_forward, 'oracle/mprnet_oracle.py')
 
 
 def main_agent_chain(args):
@@ -526,7 +556,7 @@ def main_agent_chain(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4', 'xrestormer720p', 'agent_chain'],
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'nafnet512', 'swinir_x4', 'xrestormer720p', 'mprnet720p', 'agent_chain'],
                     help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = configs[1]; swinir_x4 = configs[3]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -546,6 +576,8 @@ def main():
         return main_swinir(args)
     if args.workload == 'xrestormer720p':
         return main_xrestormer(args)
+    if args.workload == 'mprnet720p':
+        return main_mprnet(args)
     if args.workload == 'agent_chain':
         return main_agent_chain(args)
 

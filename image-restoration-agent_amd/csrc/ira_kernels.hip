@@ -1404,13 +1404,18 @@ template <int MODE>
 static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W, const float* bias,
                                    const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB, float slope) {
     const long waves = (long)T * (((long)H * Wd + 31) / 32);
-    const int NBW = NB >= 6 ? 6 : (NB >= 3 ? 3 : (NB == 2 ? 2 : 1));
+    // row blocks per workgroup: the fewest passes over the pixel operand with at most 6 blocks in registers, split evenly
+    // (NB = 4 ran as 3 + 1 before: the second pass re-read and re-converted every pixel for a third of the MFMA work)
+    const int passes = (NB + 5) / 6;
+    int NBW = (NB + passes - 1) / passes;
+    if (NBW == 5) NBW = 6;
     const dim3 grid(grid1d(waves, 4), (NB + NBW - 1) / NBW), block(256);
     static const int lds_env = env_int("IRA_CONV_LDS", 1);
     if (lds_env && NB >= 2) {      // every multi-block conv: weights through LDS
         switch (NBW) {
             case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
             case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 4: hipLaunchKernelGGL((k_conv3x3_lds<4, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
             default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
         }
         return hipGetLastError();

@@ -36,9 +36,15 @@ __global__ __launch_bounds__(256) void k_mpr_ca(const float* __restrict__ part, 
     float* hid = lds + Cp;
     const int t = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < Cp; c += 256) {
-        float a = 0.f;
-        for (int b = 0; b < bpi; ++b) a += part[((long)t * bpi + b) * Cp + c];
-        mean[c] = a * inv_px;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};                     // four fixed chains: independent loads in flight, same order every run
+        const float* pp = part + (long)t * bpi * Cp + c;
+        int b = 0;
+        for (; b + 4 <= bpi; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += pp[(long)(b + u) * Cp];
+        }
+        for (; b < bpi; ++b) a[0] += pp[(long)b * Cp];
+        mean[c] = ((a[0] + a[1]) + (a[2] + a[3])) * inv_px;
     }
     __syncthreads();
     for (int j = tid; j < Cr; j += 256) {
@@ -137,7 +143,7 @@ static unsigned mpr_grid(long total, int block = 256) {
 }
 
 // z[T][Cp] of CALayer; part must hold T * mpr_ca_blocks(P) * Cp floats
-int mpr_ca_blocks(long P) { return (int)std::min<long>(64, (P + 1023) / 1024); }
+int mpr_ca_blocks(long P) { return (int)std::min<long>(2048, (P + 255) / 256); }
 
 hipError_t launch_mpr_ca(hipStream_t st, const float* x, float* part, const float* w1, const float* w2, float* z, int T, long P, int C, int Cp,
                          int Cr) {

@@ -161,7 +161,7 @@ int schedule(MCtx& c, const float* in, int T, int H, int W, float* out) {
     const size_t big = (size_t)px * std::max(np, cop);
     c.t1 = c.alloc(big);
     c.rs = c.alloc(big);
-    c.part = c.alloc((size_t)4 * T * 64 * 256);
+    c.part = c.alloc((size_t)4 * T * 2048 * 256);
     c.z = c.alloc((size_t)4 * T * 256);
 
     // ---- stage 1 (:279-300): four quadrants = 4T images of (H/2, W/2)

@@ -472,6 +472,84 @@ class Executor:
                 return
 
 
+def default_mprnet_loader(task: str, weight_dir: Optional[str] = None):
+    """MPRNet/demo.py:25-35,60: ``{task}/pretrained_models/model_{task.lower()}.pth``, key 'state_dict', optional 'module.' prefix.
+    Looks in ``weight_dir`` or $IRA_MPRNET_WEIGHTS (the reference's MPRNet directory)."""
+    from .mprnet import TASK_WEIGHT_FILE
+    root = weight_dir or os.environ.get('IRA_MPRNET_WEIGHTS', '')
+    path = os.path.join(root, TASK_WEIGHT_FILE[task])
+    if not (root and os.path.isfile(path)):
+        raise FileNotFoundError(f"MPRNet weights {TASK_WEIGHT_FILE[task]!r} not found in {root!r}; set IRA_MPRNET_WEIGHTS or pass a loader")
+    import torch
+    sd = torch.load(path, map_location='cpu')['state_dict']
+    return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+
+
+class MPRNetCache:
+    """task ('Denoising' | 'Deblurring' | 'Deraining') -> MPRNetBackend on one device."""
+
+    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
+                 backend_factory: Optional[Callable] = None, config_fn: Optional[Callable] = None):
+        self.device, self.weight_dir = device, weight_dir
+        self.loader = state_dict_loader or default_mprnet_loader
+        self.factory, self.config_fn = backend_factory, config_fn
+        self.models: dict = {}
+
+    def get(self, task: str):
+        if task not in self.models:
+            from .mprnet import task_config
+            cfg = (self.config_fn or task_config)(task)
+            sd = self.loader(task, self.weight_dir)
+            if self.factory is not None:
+                self.models[task] = self.factory(cfg, sd, self.device)
+            else:
+                from .backend import MPRNetBackend
+                self.models[task] = MPRNetBackend(cfg, sd, device=self.device)
+        return self.models[task]
+
+    def close(self):
+        for be in self.models.values():
+            if hasattr(be, 'close'):
+                be.close()
+        self.models.clear()
+
+
+_default_mprnet_cache: Optional[MPRNetCache] = None
+
+
+def default_mprnet_cache() -> MPRNetCache:
+    global _default_mprnet_cache
+    if _default_mprnet_cache is None:
+        _default_mprnet_cache = MPRNetCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+    return _default_mprnet_cache
+
+
+class MPRNet(Tool):
+    """MPRNet tool for denoising, motion deblurring and deraining (multitask_tools.py:176-204), in-process.  The reference spawns
+    ``demo.py --task T`` which loads the task's network per call and runs every image whole (demo.py:64-87)."""
+
+    def __init__(self, subtask: str, cache: Optional[MPRNetCache] = None):
+        super().__init__(tool_name='mprnet', subtask=subtask, work_dir='MPRNet', script_rel_path='demo.py')
+        from .mprnet import SUBTASK_TO_TASK
+        sub = canonical_subtask(subtask)
+        if sub not in SUBTASK_TO_TASK:
+            raise KeyError(subtask)                          # the reference's opt_dict[subtask] (:191-196)
+        self.opt_task = SUBTASK_TO_TASK[sub]
+        self._cache = cache
+
+    def _get_cmd_opts(self) -> list:
+        return ["--task", self.opt_task, "--input_dir", self.input_dir, "--result_dir", self.output_dir]
+
+    def _invoke(self, *args) -> None:
+        be = (self._cache or default_mprnet_cache()).get(self.opt_task)
+        files = sorted(p for p in Path(self.input_dir).glob('*') if p.suffix in ('.jpg', '.JPG', '.png', '.PNG'))   # demo.py:44-47
+        if not files:
+            raise Exception(f"No files found at {self.input_dir}")                                                  # demo.py:49-50
+        for src in files:
+            out = be.restore(read_image(src, gray=False), tile=None)
+            write_png(Path(self.output_dir) / (src.stem + '.png'), out)                                             # demo.py:86-87
+
+
 # subtask keys exactly as the reference registers them (executor/__init__.py:162-169)
 RESTORMER_SUBTASKS = {
     'denoising': 'denoising',
@@ -482,25 +560,29 @@ RESTORMER_SUBTASKS = {
 
 
 def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
-                   xrestormer_cache: Optional[XRestormerCache] = None) -> Executor:
-    """The tools this backend provides, under the reference's subtask keys and in the reference's toolbox order
-    (executor/denoising/__init__.py:12-19, super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39)."""
+                   xrestormer_cache: Optional[XRestormerCache] = None, mprnet_cache: Optional[MPRNetCache] = None) -> Executor:
+    """The tools this backend provides, under the reference's subtask keys and in the reference's toolbox order with the tools this
+    backend does not build (MAXIM, DiffBIR, HAT, FBCNN, DRBNet, RIDCP, DehazeFormer) left out: denoising/__init__.py:12-19,
+    motion_deblurring/__init__.py:10-15, defocus_deblurring/__init__.py:128-131, deraining/__init__.py:10-15, dehazing/__init__.py:51-56,
+    super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39."""
+    R = lambda sub: Restormer(subtask=sub, cache=cache)
+    X = lambda sub: XRestormer(sub, xrestormer_cache)
+    M = lambda sub: MPRNet(sub, mprnet_cache)
+    S = lambda sub, on: SwinIR(sub, on, swinir_cache)
     ex = Executor()
-    for key, sub in RESTORMER_SUBTASKS.items():
-        ex.register_subtask(key, [Restormer(subtask=sub, cache=cache)])
-    ex.toolbox_router['denoising'] = [SwinIR('denoising', '15', swinir_cache), SwinIR('denoising', '50', swinir_cache)] + ex.toolbox_router['denoising']
-    for key, sub in (('denoising', 'denoising'), ('motion deblurring', 'motion_deblurring'), ('deraining', 'deraining')):
-        ex.toolbox_router[key] = [XRestormer(sub, xrestormer_cache)] + ex.toolbox_router[key]      # first in every reference toolbox it is in
-    ex.register_subtask('dehazing', [XRestormer('dehazing', xrestormer_cache)])
-    ex.register_subtask('super-resolution', [XRestormer('super_resolution', xrestormer_cache), SwinIR('super_resolution', 'gan', swinir_cache),
-                                             SwinIR('super_resolution', 'psnr', swinir_cache)])
-    ex.register_subtask('jpeg compression artifact removal', [SwinIR('jpeg_compression_artifact_removal', '40', swinir_cache)])
+    ex.register_subtask('super-resolution', [X('super_resolution'), S('super_resolution', 'gan'), S('super_resolution', 'psnr')])
+    ex.register_subtask('denoising', [X('denoising'), S('denoising', '15'), S('denoising', '50'), M('denoising'), R('denoising')])
+    ex.register_subtask('motion deblurring', [R('motion_deblurring'), M('motion_deblurring'), X('motion_deblurring')])
+    ex.register_subtask('defocus deblurring', [R('defocus_deblurring')])
+    ex.register_subtask('deraining', [X('deraining'), R('deraining'), M('deraining')])
+    ex.register_subtask('dehazing', [X('dehazing')])
+    ex.register_subtask('jpeg compression artifact removal', [S('jpeg_compression_artifact_removal', '40')])
     return ex
 
 
 def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
-                 xrestormer_cache: Optional[XRestormerCache] = None) -> int:
-    """Drop-in: replace every tool named 'restormer', 'swinir_*' or 'xrestormer' in an existing
+                 xrestormer_cache: Optional[XRestormerCache] = None, mprnet_cache: Optional[MPRNetCache] = None) -> int:
+    """Drop-in: replace every tool named 'restormer', 'swinir_*', 'xrestormer' or 'mprnet' in an existing
     (reference) executor's toolboxes by the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.
     Returns the count."""
     n = 0
@@ -513,6 +595,9 @@ def install_into(reference_executor, cache: Optional[BackendCache] = None, swini
                 n += 1
             elif name == 'xrestormer' and sub in XRESTORMER_OPTS:
                 toolbox[i] = XRestormer(subtask=sub, cache=xrestormer_cache)
+                n += 1
+            elif name == 'mprnet' and sub in ('denoising', 'motion_deblurring', 'deraining'):
+                toolbox[i] = MPRNet(subtask=sub, cache=mprnet_cache)
                 n += 1
             elif name.startswith('swinir_') and sub in SWINIR_OPTS and name[7:] in SWINIR_OPTS[sub][1]:
                 toolbox[i] = SwinIR(subtask=sub, pretrained_on=name[7:], cache=swinir_cache)

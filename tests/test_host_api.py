@@ -70,8 +70,10 @@ def test_executor_registry_and_directory_protocol(tmp_path, cache):
     ex = T.build_executor(cache)
     assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining', 'super-resolution',
                            'jpeg compression artifact removal', 'dehazing'}
-    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['xrestormer', 'swinir_15', 'swinir_50', 'restormer']     # reference order
-    assert [t.tool_name for t in ex.toolbox_router['motion deblurring']] == ['xrestormer', 'restormer']
+    # reference order, minus the tools this backend does not build (denoising/__init__.py:12-19, motion_deblurring :10-15, deraining :10-15)
+    assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['xrestormer', 'swinir_15', 'swinir_50', 'mprnet', 'restormer']
+    assert [t.tool_name for t in ex.toolbox_router['motion deblurring']] == ['restormer', 'mprnet', 'xrestormer']
+    assert [t.tool_name for t in ex.toolbox_router['deraining']] == ['xrestormer', 'restormer', 'mprnet']
     assert [t.tool_name for t in ex.toolbox_router['dehazing']] == ['xrestormer']
     assert [t.tool_name for t in ex.toolbox_router['super-resolution']] == ['xrestormer', 'swinir_gan', 'swinir_psnr']
     assert [t.tool_name for t in ex.toolbox_router['jpeg compression artifact removal']] == ['swinir_40']
@@ -94,11 +96,13 @@ def test_install_into_reference_executor(cache):
 
     class RefExecutor:
         toolbox_router = {'denoising': [RefTool('xrestormer', 'denoising'), RefTool('restormer', 'denoising')],
-                          'dehazing': [RefTool('maxim', 'dehazing')]}
+                          'dehazing': [RefTool('maxim', 'dehazing')], 'deraining': [RefTool('maxim', 'deraining'), RefTool('mprnet', 'deraining')]}
         toolbox_router['super-resolution'] = [RefTool('diffbir', 'super_resolution'), RefTool('swinir_gan', 'super_resolution'),
                                               RefTool('xrestormer', 'super_resolution')]
     n = T.install_into(RefExecutor, cache)
-    assert n == 4          # restormer, swinir_gan, xrestormer (denoising), xrestormer (super-resolution, scale 4)
+    assert n == 5          # restormer, swinir_gan, xrestormer (denoising), xrestormer (super-resolution, scale 4), mprnet (deraining)
+    assert isinstance(RefExecutor.toolbox_router['deraining'][1], T.MPRNet) and RefExecutor.toolbox_router['deraining'][1].opt_task == 'Deraining'
+    assert RefExecutor.toolbox_router['deraining'][0].tool_name == 'maxim'
     assert isinstance(RefExecutor.toolbox_router['denoising'][0], T.XRestormer)
     assert RefExecutor.toolbox_router['super-resolution'][2].scale == 4
     tb = RefExecutor.toolbox_router['denoising']
@@ -280,3 +284,40 @@ def test_xrestormer_tool_contract(tmp_path):
     assert (sr.model_name, sr.padding_size, sr.scale) == ('sr_300k.pth', 16, 4)
     with pytest.raises(KeyError):
         T.XRestormer('brightening', cache=xc)
+
+
+def _empty(p):
+    p.mkdir()
+    return p
+
+
+def test_mprnet_tool_contract(tmp_path):
+    """multitask_tools.py:176-204 + MPRNet/demo.py:44-50,86-87: task option per subtask, jpg / png inputs only, '<stem>.png'."""
+    calls = []
+
+    class FakeBackend:
+        def restore(self, img, tile=None):
+            calls.append((img.shape, tile))
+            return img
+
+    loaded = []
+    cache = T.MPRNetCache(state_dict_loader=lambda task, wd: loaded.append(task) or {}, backend_factory=lambda cfg, sd, dev: FakeBackend())
+    tool = T.MPRNet('motion deblurring', cache)
+    assert (tool.tool_name, tool.subtask, tool.opt_task) == ('mprnet', 'motion deblurring', 'Deblurring')
+    assert T.MPRNet('denoising', cache).opt_task == 'Denoising' and T.MPRNet('deraining', cache).opt_task == 'Deraining'
+    with pytest.raises(KeyError):
+        T.MPRNet('dehazing', cache)
+    inp = tmp_path / 'in'; inp.mkdir()
+    out = tmp_path / 'out'; out.mkdir()
+    Image.fromarray(_img(seed=1)).save(inp / 'a.png')
+    tool(inp, out, silent=True)
+    assert sorted(p.name for p in out.glob('*')) == ['output.png'] and len(calls) == 1 and calls[0][1] is None   # tool.py:56-62 renames a.png
+    out_b = tmp_path / 'out_b'; out_b.mkdir()
+    tool(inp, out_b, silent=True)
+    assert loaded == ['Deblurring']                      # the network is built once per task, not per call
+    other = tmp_path / 'other'; other.mkdir()
+    (other / 'a.bmp').write_bytes(b'x')                  # demo.py globs jpg / png only
+    with pytest.raises(Exception, match='No files found'):
+        tool(other, _empty(tmp_path / 'out_c'), silent=True)
+    from ira_amd.mprnet import task_config
+    assert (task_config('Deraining').n_feat, task_config('Deraining').scale_orsnetfeats) == (40, 16)
