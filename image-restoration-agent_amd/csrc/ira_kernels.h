@@ -50,6 +50,7 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const 
 hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out,
                         int T, int H, int W, int ic, int C, int relu = 0);
 
+hipError_t launch_sum_records(hipStream_t st, const float* part, int S, int reclen, float* out);   // out[i] = sum_s part[s][i]
 hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx);
 
 // tiler

@@ -1388,6 +1388,26 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
     return hipGetLastError();
 }
 
+// out[i] = sum over the S records of part[s][i], fixed order (the strip-parallel whole-frame path ships ONE Gram record per rank)
+__global__ __launch_bounds__(256) void k_sum_records(const float* __restrict__ part, int S, int reclen, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= reclen) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += part[(long)(s + u) * reclen + i];
+    }
+    for (; s < S; ++s) a[0] += part[(long)s * reclen + i];
+    out[i] = (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+hipError_t launch_sum_records(hipStream_t st, const float* part, int S, int reclen, float* out) {
+    if (S <= 0 || reclen <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sum_records, dim3((reclen + 255) / 256), dim3(256), 0, st, part, S, reclen, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, float* attn_scratch,
                            void* M, int T, int C, int heads, int S, int NB) {
     const int c = C / heads;

@@ -115,6 +115,10 @@ struct ira_model {
     float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
     float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
     bool use_fused_ffn = true;
+    // strip-parallel whole-frame forward (ira_strip_*): this rank's band of rows with halo rows of its neighbours
+    bool strip_set = false, strip_on = false;
+    ira_strip_comm scomm{};
+    int strip_top = 0, strip_bot = 0;     // halo rows at level 1 (0 or 8)
     void *qkvp, *qk, *v, *hp, *g, *M;
     int max_batch = 0;
     // harness scratch
@@ -196,6 +200,7 @@ int ensure_scratch(ira_model* m, size_t bytes);                                 
 // per-architecture: bind the device pointers of the weight blob; enqueue one forward on float32 NHWC device tensors
 bool restormer_bind_weights(ira_model* m);
 int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
+int restormer_strip_forward_enqueue(ira_model* m, const float* in, int H, int W, int halo_top, int halo_bot, float* out);
 bool naf_bind_weights(ira_model* m);
 int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool dn_bind_weights(ira_model* m);

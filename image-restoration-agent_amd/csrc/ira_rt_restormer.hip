@@ -183,10 +183,50 @@ static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const fl
     return IRA_OK;
 }
 
+// ---- strip-parallel whole-frame mode (the denoising service's default is the untiled frame, model_services.yaml:74).
+// This rank holds a band of rows of the frame plus 8 >> level halo rows of each neighbour (so the band stays aligned to the U-Net
+// grid); beyond the halo the kernels see their usual zero padding, so only interior rows are right after a kernel with a 3x3 footprint.
+// Before every such kernel the ONE halo row next to the interior is refreshed from the neighbour's edge row; the other halo rows only
+// ever feed halo outputs.  Edge rows are staged in the comm buffers and handed to the host's exchange callback (torch.distributed send /
+// recv over RCCL).
+static int strip_halo(ira_model* m, float* x, int H, int W, int C, int lv) {
+    if (!m->strip_on) return IRA_OK;
+    const ira_strip_comm& cm = m->scomm;
+    const int top = m->strip_top >> lv, bot = m->strip_bot >> lv;
+    if (top == 0 && bot == 0) return IRA_OK;
+    const size_t row = (size_t)W * C, nbytes = row * sizeof(float);
+    if (nbytes > cm.edge_capacity) return m->fail(IRA_ERR_ARG, "strip halo row of %zu bytes exceeds edge_capacity %zu", nbytes, (size_t)cm.edge_capacity);
+    if (top) HIP_TRY(m, hipMemcpyAsync(cm.send_top, x + (size_t)top * row, nbytes, hipMemcpyDeviceToDevice, m->st));
+    if (bot) HIP_TRY(m, hipMemcpyAsync(cm.send_bot, x + (size_t)(H - bot - 1) * row, nbytes, hipMemcpyDeviceToDevice, m->st));
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    if (cm.exchange(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip halo exchange callback failed");
+    if (top) HIP_TRY(m, hipMemcpyAsync(x + (size_t)(top - 1) * row, cm.recv_top, nbytes, hipMemcpyDeviceToDevice, m->st));
+    if (bot) HIP_TRY(m, hipMemcpyAsync(x + (size_t)(H - bot) * row, cm.recv_bot, nbytes, hipMemcpyDeviceToDevice, m->st));
+    return IRA_OK;
+}
+
+// Gram of the interior rows only, one summed record per rank, all-gathered: every rank then adds the same `world` records in the same
+// order, so all ranks fold the SAME attention matrix (an all-reduce would leave that to the collective's reduction order).
+static int strip_gram_mix(ira_model* m, const Blk& b, int H, int W, int C, int heads, int lv, const char* kg, const char* km) {
+    const ira_strip_comm& cm = m->scomm;
+    const int top = m->strip_top >> lv, bot = m->strip_bot >> lv, c = C / heads;
+    const long bpr = (W + 7) / 8, nblk = (long)(H - top - bot) * bpr;
+    const int S = gram_splits(1, heads, nblk), reclen = heads * (c * c + 2 * c), NBc = up32(C) / 32;
+    const size_t nbytes = (size_t)reclen * sizeof(float);
+    if (nbytes > cm.gather_capacity) return m->fail(IRA_ERR_ARG, "strip Gram record of %zu bytes exceeds gather_capacity %zu", nbytes, (size_t)cm.gather_capacity);
+    const _Float16* qk = (const _Float16*)m->qk + (size_t)top * bpr * 2 * C * 8;       // [nblk][2C][8]: rows are runs of bpr blocks
+    RUN(m, kg, ira::launch_gram(m->st, qk, m->part, 1, (int)nblk, C, heads, S));
+    RUN(m, kg, ira::launch_sum_records(m->st, m->part, S, reclen, (float*)cm.gather_send));
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    if (cm.allgather(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip Gram all-gather callback failed");
+    RUN(m, km, ira::launch_attn_mix(m->st, (const float*)cm.gather_recv, b.wo, b.temp, m->attnA, m->M, 1, C, heads, cm.world, NBc));
+    return IRA_OK;
+}
+
 // ---- one TransformerBlock: x += attn(LN1(x)); x += ffn(LN2(x))   (restormer_arch.py:146-150)
 // x: current residual stream buffer; alt: a second buffer of the same size (or nullptr).  The fused FFN writes
 // x -> alt and the two are swapped, so on return x still names the buffer holding the block's output.
-static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp) {
+static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, int H, int W, int C, int heads, int Hp, int lv) {
     const int P = H * W;
     char k_[5][64];
     if (m->profile) {
@@ -201,6 +241,8 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     const int S = gram_splits(T, heads, nblk);
     hipStream_t st = m->st;
     // MDTA (:111-132)
+    int rc = strip_halo(m, x, H, W, C, lv);
+    if (rc != IRA_OK) return rc;
     if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
         char kq[64];
         if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
@@ -209,11 +251,16 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
         RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
         RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
     }
-    RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-    RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
+    if (m->strip_on) {
+        if ((rc = strip_gram_mix(m, b, H, W, C, heads, lv, k_[2], k_[3])) != IRA_OK) return rc;
+    } else {
+        RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
+        RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
+    }
     RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
     // GDFN (:88-93)
-    int rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp);
+    if ((rc = strip_halo(m, x, H, W, C, lv)) != IRA_OK) return rc;
+    rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp);
     if (rc != IRA_OK || !m->xr) return rc;
     // X-Restormer (xrestormer_arch.py:260-261): x += OCAB(norm3(x)); x += spatial_ffn(norm4(x))
     const int sheads = m->xr_spatial_heads[b.level], inner = 16 * sheads, NBo = up32(3 * inner) / 32;
@@ -230,9 +277,9 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     return run_ffn(m, b.pin2_w, b.pin2_b, b.dw3_w, b.dw3_b, b.pout2_w, b.pout2_b, x, alt, T, H, W, C, Hp);
 }
 
-static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp) {
+static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp, int lv) {
     for (const Blk& b : blks) {
-        int rc = run_block(m, b, x, alt, T, H, W, C, heads, Hp);
+        int rc = run_block(m, b, x, alt, T, H, W, C, heads, Hp, lv);
         if (rc != IRA_OK) return rc;
     }
     return IRA_OK;
@@ -265,28 +312,50 @@ int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W
 
     float *e1 = m->xe1, *e2 = m->xe2, *e3 = m->xe3, *l4 = m->x4, *d3 = m->xd3, *d2 = m->xd2, *d1 = m->xd1;
     RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, e1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
-    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0]))) return rc;                         // :248
+    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0], 0))) return rc;                         // :248
+    if ((rc = strip_halo(m, e1, g.H[0], g.W[0], g.C[0], 0))) return rc;
     RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
-    if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1], 1))) return rc;
+    if ((rc = strip_halo(m, e2, g.H[1], g.W[1], g.C[1], 1))) return rc;
     RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e2, m->down23, nullptr, nullptr, e3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
-    if ((rc = run_stage(m, m->enc3, e3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    if ((rc = run_stage(m, m->enc3, e3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2], 2))) return rc;
+    if ((rc = strip_halo(m, e3, g.H[2], g.W[2], g.C[2], 2))) return rc;
     RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e3, m->down34, nullptr, nullptr, l4, 1, T, g.H[2], g.W[2], g.C[2], g.C[2] / 2, nb(g.C[2] / 2)));
-    if ((rc = run_stage(m, m->lat, l4, nullptr, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3]))) return rc;                         // :257
+    if ((rc = run_stage(m, m->lat, l4, nullptr, T, g.H[3], g.W[3], g.C[3], g.heads[3], g.Hp[3], 3))) return rc;                         // :257
 
+    if ((rc = strip_halo(m, l4, g.H[3], g.W[3], g.C[3], 3))) return rc;
     RUN(m, "conv3x3_up", ira::launch_conv3x3(st, l4, m->up43, nullptr, nullptr, m->u3, 2, T, g.H[3], g.W[3], g.C[3], g.C[3] * 2, nb(g.C[3] * 2)));         // :259
     RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u3, g.C[2], e3, g.C[2], true, m->red3, 0, m->red3_b, nullptr, d3, g.C[2], nb(g.C[2]), T, (int)g.P[2]));   // :260-261
-    if ((rc = run_stage(m, m->dec3, d3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2]))) return rc;
+    if ((rc = run_stage(m, m->dec3, d3, nullptr, T, g.H[2], g.W[2], g.C[2], g.heads[2], g.Hp[2], 2))) return rc;
+    if ((rc = strip_halo(m, d3, g.H[2], g.W[2], g.C[2], 2))) return rc;
     RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d3, m->up32, nullptr, nullptr, m->u2, 2, T, g.H[2], g.W[2], g.C[2], g.C[2] * 2, nb(g.C[2] * 2)));
     RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], e2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, d2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
-    if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1]))) return rc;
+    if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1], 1))) return rc;
+    if ((rc = strip_halo(m, d2, g.H[1], g.W[1], g.C[1], 1))) return rc;
     RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
     RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], e1, g.C[0], d1, (long)T * g.P[0]));                                        // :270
     float* a1 = m->ad1;
-    if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                              // :271
+    if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1], 0))) return rc;                              // :271
     a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
-    if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1]))) return rc;                            // :273
+    if ((rc = run_stage(m, m->refine, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1], 0))) return rc;                            // :273
+    if ((rc = strip_halo(m, d1, g.H[0], g.W[0], g.C[1], 0))) return rc;
     RUN(m, "conv3x3_out", ira::launch_conv3x3(st, d1, m->out_w, m->out_b, in, out, 3, T, g.H[0], g.W[0], g.C[1], c.out_channels, nb(c.out_channels)));   // :281
     return IRA_OK;
+}
+
+// One rank's band of a whole frame: in / out are the LOCAL images (halo rows included), T = 1.
+int restormer_strip_forward_enqueue(ira_model* m, const float* in, int H, int W, int halo_top, int halo_bot, float* out) {
+    if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "strip forward: Restormer models only");
+    if (!m->strip_set) return m->fail(IRA_ERR_ARG, "strip forward: call ira_strip_configure first");
+    if ((halo_top != 0 && halo_top != 8) || (halo_bot != 0 && halo_bot != 8) || H - halo_top - halo_bot < 8)
+        return m->fail(IRA_ERR_ARG, "strip forward: halos must be 0 or 8 rows and leave >= 8 interior rows (H=%d top=%d bot=%d)", H, halo_top, halo_bot);
+    const ira_strip_comm& cm = m->scomm;
+    if ((halo_top != 0) != (cm.rank > 0) || (halo_bot != 0) != (cm.rank < cm.world - 1))
+        return m->fail(IRA_ERR_ARG, "strip forward: rank %d of %d must have a top halo iff it has an upper neighbour, and likewise below", cm.rank, cm.world);
+    m->strip_on = true; m->strip_top = halo_top; m->strip_bot = halo_bot;
+    const int rc = restormer_forward_enqueue(m, in, 1, H, W, out);
+    m->strip_on = false;
+    return rc;
 }
 
 }  // namespace ira_rt

@@ -387,6 +387,45 @@ int ira_forward_device(ira_model_t* m, const float* in, int B, int H, int W, flo
     return IRA_OK;
 }
 
+int ira_strip_configure(ira_model_t* m, const ira_strip_comm* comm) {
+    ENTER(m);
+    if (comm == nullptr) { m->strip_set = false; return IRA_OK; }
+    if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "ira_strip_configure: Restormer handles only");
+    if (!comm->exchange || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
+        return m->fail(IRA_ERR_ARG, "ira_strip_configure: callbacks must be set and 0 <= rank < world");
+    if (!comm->gather_send || !comm->gather_recv || (comm->world > 1 && (!comm->send_top || !comm->recv_top || !comm->send_bot || !comm->recv_bot)))
+        return m->fail(IRA_ERR_ARG, "ira_strip_configure: NULL staging buffer");
+    m->scomm = *comm;
+    m->strip_set = true;
+    return IRA_OK;
+}
+
+int ira_strip_buffer_bytes(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_t* record_bytes) {
+    ENTER(m);
+    if (m->arch != 0 || m->xr || Wp <= 0 || !edge_bytes || !record_bytes) return m->fail(IRA_ERR_ARG, "ira_strip_buffer_bytes: Restormer handle, Wp > 0");
+    const ira_restormer_config& c = m->cfg;
+    uint64_t rec = 0, edge = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int C = c.dim << l, ch = C / c.heads[l];
+        rec = std::max<uint64_t>(rec, (uint64_t)c.heads[l] * (ch * ch + 2 * ch) * 4);
+        edge = std::max<uint64_t>(edge, (uint64_t)(Wp >> l) * C * 4);
+    }
+    const int C1 = 2 * c.dim, ch1 = C1 / c.heads[0];             // decoder level 1 and refinement run at 2 * dim (:232-235)
+    rec = std::max<uint64_t>(rec, (uint64_t)c.heads[0] * (ch1 * ch1 + 2 * ch1) * 4);
+    edge = std::max<uint64_t>(edge, (uint64_t)Wp * C1 * 4);
+    *edge_bytes = edge; *record_bytes = rec;
+    return IRA_OK;
+}
+
+int ira_strip_forward_device(ira_model_t* m, const float* in, int H, int W, int halo_top, int halo_bot, float* out) {
+    ENTER(m);
+    if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_strip_forward_device: NULL buffer");
+    int rc = restormer_strip_forward_enqueue(m, in, H, W, halo_top, halo_bot, out);
+    if (rc != IRA_OK) return rc;
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
 int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, float* out) {
     ENTER(m);
     if (!in || !out) return m->fail(IRA_ERR_ARG, "ira_forward: NULL buffer");

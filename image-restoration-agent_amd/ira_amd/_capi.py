@@ -61,6 +61,15 @@ class IraMprnetConfig(C.Structure):
                 ('scale_orsnetfeats', C.c_int32), ('num_cab', C.c_int32), ('reduction', C.c_int32), ('prelu', C.c_float)]
 
 
+STRIP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+
+
+class IraStripComm(C.Structure):
+    _fields_ = [('ctx', C.c_void_p), ('exchange', STRIP_FN), ('allgather', STRIP_FN), ('rank', C.c_int32), ('world', C.c_int32),
+                ('send_top', C.c_void_p), ('recv_top', C.c_void_p), ('send_bot', C.c_void_p), ('recv_bot', C.c_void_p),
+                ('edge_capacity', C.c_uint64), ('gather_send', C.c_void_p), ('gather_recv', C.c_void_p), ('gather_capacity', C.c_uint64)]
+
+
 _vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 _pi = C.POINTER(C.c_int)
 
@@ -78,6 +87,9 @@ SIGNATURES = {
     'ira_sync': (_i, [_vp]),
     'ira_forward': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'ira_forward_device': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'ira_strip_configure': (_i, [_vp, C.POINTER(IraStripComm)]),
+    'ira_strip_buffer_bytes': (_i, [_vp, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    'ira_strip_forward_device': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'ira_tile_plan': (_i, [_i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi]),
     'ira_model_tile_plan': (_i, [_vp, _i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi, _pi]),
     'ira_restore_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -87,6 +87,19 @@ class _Backend:
         """float32 NHWC device tensors (raw pointers, e.g. torch.Tensor.data_ptr())."""
         self._ck(self._lib.ira_forward_device(self._h, in_ptr, B, H, W, out_ptr), 'ira_forward_device')
 
+    # -- strip-parallel whole frame (SURVEY 8 row f2; host side: ira_amd/dist.py::StripParallelRestorer)
+    def strip_buffer_bytes(self, Wp: int):
+        e, r = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._lib.ira_strip_buffer_bytes(self._h, int(Wp), C.byref(e), C.byref(r)), 'ira_strip_buffer_bytes')
+        return e.value, r.value
+
+    def strip_configure(self, comm):
+        """comm: _capi.IraStripComm (kept alive by the caller) or None."""
+        self._ck(self._lib.ira_strip_configure(self._h, C.byref(comm) if comm is not None else None), 'ira_strip_configure')
+
+    def strip_forward_device(self, in_ptr: int, H_local: int, W: int, halo_top: int, halo_bot: int, out_ptr: int):
+        self._ck(self._lib.ira_strip_forward_device(self._h, in_ptr, H_local, W, halo_top, halo_bot, out_ptr), 'ira_strip_forward_device')
+
     # -- harness
     def restore(self, img_u8: np.ndarray, tile=None, tile_overlap: int = 32) -> np.ndarray:
         """uint8 (h,w,c) -> uint8 (h,w,c): pad -> whole/tiled forward -> average -> clamp -> crop -> uint8

@@ -38,6 +38,7 @@ extern "C" {
 #define IRA_ERR_HIP        3
 #define IRA_ERR_WEIGHTS    4
 #define IRA_ERR_OOM        5
+#define IRA_ERR_COMM       6   /* a strip-parallel exchange callback returned non-zero */
 
 typedef struct ira_model ira_model_t;
 
@@ -203,6 +204,38 @@ int ira_restore_padcrop_u8(ira_model_t* model, const uint8_t* in_hwc_host, int h
  * ira_restore_tiles_device are then (n, tile_h*scale, tile_w*scale, c) and ira_blend_tiles_device writes (h*scale, w*scale, c)). */
 int ira_model_tile_plan(ira_model_t* model, int h, int w, int tile, int overlap,
                         int* Hp, int* Wp, int* tile_h, int* tile_w, int* n_rows, int* n_cols, int* scale);
+
+/* ---- Whole-frame (untiled) Restormer split over the GPUs of a node.  The reference's denoising service runs the
+ * frame untiled by default (ModelService/model_services.yaml:74; model_serving.py:170-176), on one GPU.  Here rank r of `world` holds
+ * rows [r0, r1) of the (padded) frame, r0 and r1 multiples of 8, plus 8 halo rows of each neighbour; ira_strip_forward_device runs
+ * Restormer.forward (restormer_arch.py:245-284) on that band and calls back into the host at the two kinds of exchange step the
+ * network has:
+ *   exchange(ctx, nbytes):  send send_top[0:nbytes] to rank-1 and send_bot[0:nbytes] to rank+1 (where they exist), receive recv_top
+ *                           from rank-1 and recv_bot from rank+1; one row of the feature map before every 3x3 / depthwise 3x3
+ *                           (restormer_arch.py:85,108,160,174,184,243): 95 calls per forward.
+ *   allgather(ctx, nbytes): gather gather_send[0:nbytes] of every rank into gather_recv, rank-major; the per-block Gram q k^T and the
+ *                           squared norms of q and k over this rank's pixels (:121-124): 44 calls per forward.
+ * All buffers are device memory owned by the caller (torch tensors); a callback returns 0 once the received bytes are visible to the
+ * device.  The host side is ira_amd/dist.py::StripParallelRestorer (torch.distributed over RCCL). */
+typedef int (*ira_strip_exchange_fn)(void* ctx, size_t nbytes);
+typedef struct ira_strip_comm {
+    void* ctx;
+    ira_strip_exchange_fn exchange, allgather;
+    int32_t rank, world;
+    void *send_top, *recv_top, *send_bot, *recv_bot;
+    uint64_t edge_capacity;                       /* bytes of each of the four edge buffers: >= Wp * 2 * dim * 4 */
+    void *gather_send, *gather_recv;
+    uint64_t gather_capacity;                     /* bytes of gather_send (gather_recv holds world times that): >= ira_strip_record_bytes */
+} ira_strip_comm;
+
+/* Install (or, with comm == NULL, remove) the exchange callbacks of a Restormer handle. */
+int ira_strip_configure(ira_model_t* model, const ira_strip_comm* comm);
+/* Largest Gram record (bytes) and largest edge row (bytes, for a padded frame width Wp) the model's forward will stage. */
+int ira_strip_buffer_bytes(ira_model_t* model, int Wp, uint64_t* edge_bytes, uint64_t* record_bytes);
+/* in / out: float32 NHWC device images of H_local = halo_top + rows + halo_bot rows by W columns; halo_top / halo_bot are 8 where the
+ * rank has a neighbour on that side and 0 at the frame border.  Rows [halo_top, H_local - halo_bot) of out are this rank's result. */
+int ira_strip_forward_device(ira_model_t* model, const float* in_local_nhwc_dev, int H_local, int W,
+                             int halo_top, int halo_bot, float* out_local_nhwc_dev);
 
 /* Sharded form for one-process-per-GPU tile parallelism.  All pointers are device
  * memory.  frame: uint8 (h,w,c), unpadded.  Runs tiles [first_tile, first_tile+n_tiles) of the

@@ -155,3 +155,91 @@ def test_block_partition_covers_in_order():
                 got += list(range(first, first + count))
             assert got == list(range(n))
     assert block_partition(40, 8, 3) == (15, 5, 5)      # 5 tiles per GPU at 4K on 8 GPUs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Strip-parallel whole frame: the host side (band bounds, halo rows, the two exchange callbacks over torch.distributed,
+# assembly) with a CPU stand-in for libira_hip's band forward that has the same two needs as Restormer: a 3x3 footprint (one halo row
+# refreshed through comm.exchange) and a whole-frame statistic (one record per rank through comm.allgather).
+
+class CpuStripBackend:
+    def strip_buffer_bytes(self, Wp):
+        return Wp * 3 * 4, 8
+
+    def strip_configure(self, comm):
+        self.comm = comm
+
+    @staticmethod
+    def _arr(ptr, shape, dtype=np.float32):
+        import ctypes as C
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
+
+    def strip_forward_device(self, in_ptr, H, W, top, bot, out_ptr):
+        cm = self.comm
+        x = self._arr(in_ptr, (H, W, 3)).copy()
+        row = W * 3 * 4
+        if top:
+            x[:top] = np.nan                                                   # halo rows arrive through the exchange only
+            self._arr(cm.send_top, (W, 3))[:] = x[top]
+        if bot:
+            x[H - bot:] = np.nan
+            self._arr(cm.send_bot, (W, 3))[:] = x[H - bot - 1]
+        if top or bot:
+            assert cm.exchange(cm.ctx, row) == 0
+        if top:
+            x[top - 1] = self._arr(cm.recv_top, (W, 3))
+        if bot:
+            x[H - bot] = self._arr(cm.recv_bot, (W, 3))
+        inner = x[top:H - bot]
+        self._arr(cm.gather_send, (1,), np.int64)[0] = int((inner > 0.5).sum())
+        assert cm.allgather(cm.ctx, 8) == 0
+        total = int(self._arr(cm.gather_recv, (cm.world,), np.int64).sum())
+        xz = np.pad(np.nan_to_num(x, nan=0.0), ((1, 1), (1, 1), (0, 0)))
+        box = sum(xz[dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)) / 9.0
+        y = np.where(np.isnan(x), 0.0, box) * 0.75 + 0.25 * ((total % 97) / 97.0)
+        self._arr(out_ptr, (H, W, 3))[:] = y.astype(np.float32)
+
+
+def _strip_worker(rank, world, port, h, w, q):
+    import torch.distributed as dist
+    from ira_amd.dist import StripParallelRestorer, TorchDistTransport
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _, noisy = O.synthetic_noisy_image(h, w, 3, seed=8)
+    rst = StripParallelRestorer(CpuStripBackend(), rank, world, transport=TorchDistTransport(rank, world))
+    out = rst.restore_frame(torch.from_numpy(noisy))
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,h,w', [(2, 45, 52), (3, 72, 40), (2, 16, 24)])
+def test_strip_parallel_matches_single_process(world, h, w):
+    from ira_amd.dist import StripParallelRestorer
+    _, noisy = O.synthetic_noisy_image(h, w, 3, seed=8)
+    single = StripParallelRestorer(CpuStripBackend(), 0, 1).restore_frame(torch.from_numpy(noisy)).numpy()
+    assert single.shape == (h, w, 3)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert np.array_equal(results[r], single), r
+
+
+def test_strip_bounds():
+    from ira_amd.dist import strip_bounds
+    assert strip_bounds(2160, 8)[0] == (0, 272) and strip_bounds(2160, 8)[-1] == (1896, 2160)     # 270 groups of 8 rows: 6 x 34 + 2 x 33
+    for Hp, world in ((2160, 1), (2160, 3), (64, 8), (72, 4)):
+        b = strip_bounds(Hp, world)
+        assert b[0][0] == 0 and b[-1][1] == Hp and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all((e - s) % 8 == 0 and e > s for s, e in b)
+    with pytest.raises(ValueError):
+        strip_bounds(24, 4)
