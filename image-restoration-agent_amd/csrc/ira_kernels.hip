@@ -1005,6 +1005,155 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense 3x3 with the PIXEL operand staged through LDS as well.  k_conv3x3_lds loads and splits (fp32 -> fp16 hi + lo) every
+// pixel's 16 channels of a k-step once per TAP: nine times the loads and nine times the conversion VALU work of the 3 * NBW MFMAs
+// they feed.  Here a workgroup owns an 8 x 16 pixel tile (wave w: rows 2w, 2w + 1): per k-step the 10 x 18 halo tile is read and
+// split ONCE into LDS ([plane][k half][pixel] x 16 B: a wave's B fragment of any tap is 2 runs of 16 consecutive 16-byte slots,
+// conflict-free), loaded a k-step ahead of its use; the nine taps then read their fragments at shifted tile offsets.  Same
+// operands, same MFMA order as k_conv3x3_lds: bitwise the same output.
+template <int NBW, int MODE>
+__global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ in, const f16* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ skip,
+                                                      float* __restrict__ out, int T, int H, int Wd, int K, int N,
+                                                      int NBtot, float slope) {
+    constexpr int F = 2 * NBW;
+    constexpr int SH = (F + 3) / 4;
+    constexpr int TH = 8, TW = 16, HX = TW + 2, NQ = (TH + 2) * HX;   // 180 halo pixels
+    constexpr int NE = NQ * 4, BI = (NE + 255) / 256;                  // float4 elements of one k-step of the halo tile
+    __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
+    __shared__ __attribute__((aligned(16))) half8 bt[2][2][2][NQ];    // [buffer][plane hi / lo][k half][halo pixel]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_x = (Wd + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int t = (int)(tile / ((long)tiles_y * tiles_x));
+    const int trem = (int)(tile - (long)t * tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int py = 2 * wave + (r >> 4), pxx = r & 15;
+    const int y = y0 + py, x = x0 + pxx;
+    const bool valid = y < H && x < Wd;
+    const int P = H * Wd, p = y * Wd + x;
+    const int nb0 = blockIdx.y * NBW;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        acc[nb] = zero16();
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        }
+    }
+    const int KT = K >> 4;
+    const int nsteps = 9 * KT;
+    const long lo_off = 9L * NBtot * KT * 512;
+    auto gsrc = [&](int step, int f) -> const half8* {
+        const int s = step / 9, tap = step - 9 * s;
+        int nb = nb0 + (f < NBW ? f : f - NBW);
+        if (nb >= NBtot) nb = NBtot - 1;
+        return (const half8*)(W + (f < NBW ? 0 : lo_off) + (((long)tap * NBtot + nb) * KT + s) * 512 + lane * 8);
+    };
+    // halo-tile element e of a k-step: pixel q = e / 4 (row q / 18 - 1, column q % 18 - 1 of the tile), channels 4 * (e % 4) .. + 3
+    f32x4 bst[BI];
+    auto bload = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < NE) {
+                const int q = e >> 2, c4 = e & 3;
+                const int yy = y0 + q / HX - 1, xx = x0 + q % HX - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) v = *(const f32x4*)(in + ((long)(t * H + yy) * Wd + xx) * K + 16 * s + 4 * c4);
+            }
+            bst[i] = v;
+        }
+    };
+    auto bstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            if (e < NE) {
+                const int q = e >> 2, c4 = e & 3;
+                half4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { hi[j] = (f16)bst[i][j]; lo[j] = (f16)(bst[i][j] - (float)hi[j]); }
+                half4* dh = (half4*)&bt[buf][0][c4 >> 1][q] + (c4 & 1);
+                half4* dl = (half4*)&bt[buf][1][c4 >> 1][q] + (c4 & 1);
+                *dh = hi; *dl = lo;
+            }
+        }
+    };
+    half8 stg[SH];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(0, wave + 4 * i);
+    bload(0);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[0][wave + 4 * i][lane] = stg[i];
+    bstore(0);
+    __syncthreads();
+
+    for (int s = 0; s < KT; ++s) {
+        const int bb = s & 1;
+        if (s + 1 < KT) bload(s + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = 9 * s + tap;
+            if (step + 1 < nsteps) {
+#pragma unroll
+                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(step + 1, wave + 4 * i);
+            }
+            const int q = (py + tap / 3) * HX + pxx + tap % 3;
+            const half8 b = bt[bb][0][h][q], bl = bt[bb][1][h][q];
+            const int cur = step & 1;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                if (nb0 + nb < NBtot) {
+                    const half8 a = wl[cur][nb][lane], al = wl[cur][NBW + nb][lane];
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+                }
+            }
+            if (step + 1 < nsteps) {
+#pragma unroll
+                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[cur ^ 1][wave + 4 * i][lane] = stg[i];
+            }
+            if (tap == 8 && s + 1 < KT) bstore(bb ^ 1);
+            __syncthreads();
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                if (n >= N) continue;
+                const float val = acc[nb][8 * u + j];
+                if constexpr (MODE == 0) {
+                    out[((long)t * P + p) * N + n] = val;
+                } else if constexpr (MODE == 4) {
+                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
+                } else if constexpr (MODE == 1) {
+                    const int oc = n * 4 + (y & 1) * 2 + (x & 1);
+                    out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
+                } else if constexpr (MODE == 2) {
+                    const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                } else {
+                    const long o = ((long)t * P + p) * N + n;
+                    out[o] = val + skip[o];
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
 // OverlapPatchEmbed (restormer_arch.py:156-165): 3x3 conv from 1/3 input channels, fp32 VALU (exact
 // fp32 like the reference; 0.1% of the FLOPs).  One thread = one pixel x 8 output channels.
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, const float* __restrict__ w,
@@ -1431,6 +1580,22 @@ static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W
     if (NBW == 5) NBW = 6;
     const dim3 grid(grid1d(waves, 4), (NB + NBW - 1) / NBW), block(256);
     static const int lds_env = env_int("IRA_CONV_LDS", 1);
+    static const int tile_env = env_int("IRA_CONV_TILE", 1);
+    // weights AND pixels through LDS (8 x 16 pixel tiles) where a k-step carries enough MFMAs to pay for the tile staging and its
+    // barriers: measured faster for >= 3 row blocks and K >= 96 (MPRNet CABs, Restormer up-convolutions), slower for the 64-channel
+    // SwinIR upsampler and the 2-block convolutions
+    static const int tile_min_nbw = env_int("IRA_CONV_TILE_MINNBW", 3), tile_min_kt = env_int("IRA_CONV_TILE_MINKT", 6);
+    if (tile_env && lds_env && NBW >= tile_min_nbw && (K >> 4) >= tile_min_kt) {
+        const long tiles = (long)T * ((H + 7) / 8) * ((Wd + 15) / 16);
+        const dim3 tgrid((unsigned)tiles, (NB + NBW - 1) / NBW);
+        switch (NBW) {
+            case 2: hipLaunchKernelGGL((k_conv3x3_tile<2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 3: hipLaunchKernelGGL((k_conv3x3_tile<3, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 4: hipLaunchKernelGGL((k_conv3x3_tile<4, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            default: hipLaunchKernelGGL((k_conv3x3_tile<6, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+        }
+        return hipGetLastError();
+    }
     if (lds_env && NB >= 2) {      // every multi-block conv: weights through LDS
         switch (NBW) {
             case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
