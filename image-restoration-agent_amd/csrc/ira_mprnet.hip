@@ -28,38 +28,48 @@ __global__ __launch_bounds__(256) void k_mpr_chan_partial(const float* __restric
     }
 }
 
-// CALayer step 2: mean -> 1x1 (C -> C/r) -> ReLU -> 1x1 (C/r -> C) -> sigmoid.  One workgroup per image.  z [T][Cp].
-__global__ __launch_bounds__(256) void k_mpr_ca(const float* __restrict__ part, int bpi, float inv_px, const float* __restrict__ w1,
-                                                const float* __restrict__ w2, float* __restrict__ z, int C, int Cp, int Cr) {
-    extern __shared__ float lds[];                             // mean[Cp] + hid[Cr]
+// CALayer step 2: mean -> 1x1 (C -> C/r) -> ReLU -> 1x1 (C/r -> C) -> sigmoid.  One workgroup of 1024 threads per image: the bpi partial
+// records are summed by 1024 / Cp thread groups over fixed slices (four fixed chains each), then across groups in group order.  z [T][Cp].
+__global__ __launch_bounds__(1024) void k_mpr_ca(const float* __restrict__ part, int bpi, float inv_px, const float* __restrict__ w1,
+                                                 const float* __restrict__ w2, float* __restrict__ z, int C, int Cp, int Cr) {
+    extern __shared__ float lds[];                             // mean[Cp] + hid[Cr] + red[G][Cp]
     float* mean = lds;
     float* hid = lds + Cp;
+    float* red = hid + Cr;
     const int t = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < Cp; c += 256) {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};                     // four fixed chains: independent loads in flight, same order every run
+    const int G = 1024 / Cp, g = tid / Cp, c = tid - g * Cp;
+    if (g < G) {
+        const int per = (bpi + G - 1) / G, b0 = g * per, b1 = min(bpi, b0 + per);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         const float* pp = part + (long)t * bpi * Cp + c;
-        int b = 0;
-        for (; b + 4 <= bpi; b += 4) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] += pp[(long)(b + u) * Cp];
         }
-        for (; b < bpi; ++b) a[0] += pp[(long)b * Cp];
-        mean[c] = ((a[0] + a[1]) + (a[2] + a[3])) * inv_px;
+        for (; b < b1; ++b) a[0] += pp[(long)b * Cp];
+        red[g * Cp + c] = (a[0] + a[1]) + (a[2] + a[3]);
     }
     __syncthreads();
-    for (int j = tid; j < Cr; j += 256) {
+    for (int cc = tid; cc < Cp; cc += 1024) {
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(w1[(long)j * C + c], mean[c], a);
+        for (int gg = 0; gg < G; ++gg) a += red[gg * Cp + cc];
+        mean[cc] = a * inv_px;
+    }
+    __syncthreads();
+    for (int j = tid; j < Cr; j += 1024) {
+        float a = 0.f;
+        for (int cc = 0; cc < C; ++cc) a = fmaf(w1[(long)j * C + cc], mean[cc], a);
         hid[j] = fmaxf(a, 0.f);
     }
     __syncthreads();
-    for (int c = tid; c < Cp; c += 256) {
+    for (int cc = tid; cc < Cp; cc += 1024) {
         float a = 0.f;
-        if (c < C) {
-            for (int j = 0; j < Cr; ++j) a = fmaf(w2[(long)c * Cr + j], hid[j], a);
+        if (cc < C) {
+            for (int j = 0; j < Cr; ++j) a = fmaf(w2[(long)cc * Cr + j], hid[j], a);
             a = 1.0f / (1.0f + __expf(-a));
         }
-        z[(long)t * Cp + c] = a;
+        z[(long)t * Cp + cc] = a;
     }
 }
 
@@ -153,7 +163,7 @@ hipError_t launch_mpr_ca(hipStream_t st, const float* x, float* part, const floa
     hipLaunchKernelGGL(k_mpr_chan_partial, dim3((unsigned)(T * bpi)), dim3(256), 0, st, x, part, (int)P, Cp, bpi, ppb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_mpr_ca, dim3(T), dim3(256), (size_t)(Cp + Cr) * sizeof(float), st, part, bpi, 1.0f / (float)P, w1, w2, z, C, Cp, Cr);
+    hipLaunchKernelGGL(k_mpr_ca, dim3(T), dim3(1024), (size_t)(Cp + Cr + (1024 / Cp) * Cp) * sizeof(float), st, part, bpi, 1.0f / (float)P, w1, w2, z, C, Cp, Cr);
     return hipGetLastError();
 }
 
