@@ -598,12 +598,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # IRA_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box (all ranks on GPU 0, collectives staged by gloo); never a result
+    backend = os.environ.get('IRA_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = task_config('Real_Denoising')          # LayerNorm BiasFree, demo.py:59-61
     be = RestormerBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
@@ -620,7 +627,8 @@ def main():
     if whole and world > 1:
         # the untiled frame in `world` horizontal bands, halo rows and Gram records over RCCL (ira_amd/dist.py)
         from ira_amd.dist import StripParallelRestorer
-        srst = StripParallelRestorer(be, rank, world)
+        from ira_amd.dist import TorchDistTransport
+        srst = StripParallelRestorer(be, rank, world, transport=TorchDistTransport(rank, world, via_host=backend != 'nccl'))
 
         class _Bands:
             def restore_frame(self, frame, tile, overlap, out=None):
@@ -659,7 +667,7 @@ def main():
             'metric': 'restored megapixels/sec at 4K (Restormer-denoise' + (', whole frame)' if whole else ')'), 'value': round(value, 4), 'unit': 'MP/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate + f32 residual stream', 'data': 'synthetic' + ('' if backend == 'nccl' or world == 1 else f' (REHEARSAL: {backend}, all ranks on one GPU)'),
             'config': {'workload': f'Restormer Real_Denoising (BiasFree LN, 26.1M params, seeded weights), {w}x{h} uint8 frame, '
                                    f'tile {th} overlap {args.overlap} -> {n_tiles} tiles ({computed_px / 1e6:.2f} MP computed), '
                                    + (f'{world} horizontal band(s) with halo-row and Gram exchange' if whole else f'tile-parallel over {world} GPU(s)'),

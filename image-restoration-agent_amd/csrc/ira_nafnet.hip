@@ -482,6 +482,7 @@ static hipError_t naf_pw_nbw(hipStream_t st, const void* x, int K, const f16* W,
     // at most 4 blocks per workgroup: the 8-block register tile ran one wave per SIMD (measured on the same kernel with the
     // SwinIR-L fc2 shape: 46.7 ms per frame at 8 blocks, 34.2 at 2 x 4); the pixel operand is re-read per split, from L2
     if (NBtot % 4 == 0) return naf_pw_launch<4, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
+    if (NBtot % 3 == 0) return naf_pw_launch<3, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);   // 96 / 192 channels (MPRNet)
     if (NBtot % 2 == 0) return naf_pw_launch<2, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
     return naf_pw_launch<1, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
 }

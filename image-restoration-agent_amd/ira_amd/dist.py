@@ -60,7 +60,12 @@ class TileParallelRestorer:
         if self.world > 1:
             import torch.distributed as dist
             # restore_tiles_t is host-synchronous, so `local` is complete before RCCL reads it
-            dist.all_gather_into_tensor(allt.view(-1), local[:chunk].reshape(-1), group=self.group)
+            if frame_u8.is_cuda and dist.get_backend(self.group) == 'gloo':      # rehearsal on a one-GPU box: stage through the host
+                host = torch.empty(allt.numel(), dtype=allt.dtype)
+                dist.all_gather_into_tensor(host, local[:chunk].reshape(-1).cpu(), group=self.group)
+                allt.view(-1).copy_(host)
+            else:
+                dist.all_gather_into_tensor(allt.view(-1), local[:chunk].reshape(-1), group=self.group)
             if frame_u8.is_cuda:
                 torch.cuda.synchronize(frame_u8.device)     # RCCL stream -> visible to the library stream
         if out is None:
