@@ -45,7 +45,8 @@ hipError_t launch_ffn_fused12(hipStream_t st, const float* x, float* x_out, int 
                               int T, int H, int W, int Hp);
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
-                          const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope = 0.f);
+                          const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope = 0.f,
+                          int ldin = 0, int ldout = 0);   // floats per pixel of in / of out and skip (0 = K / N)
 
 hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const float* bias, float* out,
                         int T, int H, int W, int ic, int C, int relu = 0);
@@ -113,5 +114,9 @@ hipError_t launch_mpr_sam(hipStream_t st, const float* x1, const float* y8, cons
 // wide [N][h][2w][C] <-> halves [2N][h][w][C] (half image 2n + lr); merge 0: split, 1: concatenate
 hipError_t launch_mpr_lr(hipStream_t st, float* wide, float* halves, int N, int h, int w, int C, int merge);
 hipError_t launch_mpr_up2(hipStream_t st, const float* in, const float* add, float* out, int T, int H, int W, int C);
+
+// ---- RRDBNet (ira_rrdb.hip)
+hipError_t launch_pixel_unshuffle(hipStream_t st, const float* in, float* out, int T, int H, int W, int c, int s);
+hipError_t launch_axpy_strided(hipStream_t st, const float* u, int ldu, const float* v, int ldv, float* y, int ldy, float a, int C, long npx);
 
 }  // namespace ira

@@ -804,7 +804,7 @@ template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const f16* __restrict__ W,
                                                  const float* __restrict__ bias, const float* __restrict__ skip,
                                                  float* __restrict__ out, int T, int H, int Wd, int K, int N,
-                                                 int NBtot, float slope) {
+                                                 int NBtot, float slope, int ldin, int ldout) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int P = H * Wd;
     const int chunks = (P + 31) >> 5;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-            const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h;
+            const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * ldin + 8 * h;
             const f16* wt = wbase + (long)tap * NBtot * KT * 512;
             f32x4 lo4 = *(const f32x4*)(src + 16 * s), hi4 = *(const f32x4*)(src + 16 * s + 4);
             if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
@@ -870,9 +870,9 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
                 if (n >= N) continue;
                 const float val = acc[nb][8 * u + j];
                 if constexpr (MODE == 0) {
-                    out[((long)t * P + p) * N + n] = val;
+                    out[((long)t * P + p) * ldout + n] = val;
                 } else if constexpr (MODE == 4) {
-                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
+                    out[((long)t * P + p) * ldout + n] = val > 0.f ? val : slope * val;
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
                     out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
                 } else {
-                    const long o = ((long)t * P + p) * N + n;
+                    const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
                 }
             }
@@ -893,7 +893,7 @@ template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ in, const f16* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ skip,
                                                      float* __restrict__ out, int T, int H, int Wd, int K, int N,
-                                                     int NBtot, float slope) {
+                                                     int NBtot, float slope, int ldin, int ldout) {
     constexpr int F = 2 * NBW;
     constexpr int SH = (F + 3) / 4;
     __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
         }
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-        const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * K + 8 * h + 16 * s;
+        const float* src = in + ((long)(t * H + (inb ? yy : y)) * Wd + (inb ? xx : x)) * ldin + 8 * h + 16 * s;
         f32x4 lo4 = *(const f32x4*)src, hi4 = *(const f32x4*)(src + 4);
         if (!inb) { lo4 = f32x4{0.f, 0.f, 0.f, 0.f}; hi4 = lo4; }
         const half8 b = cvt8(lo4, hi4);
@@ -988,9 +988,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
                 if (n >= N) continue;
                 const float val = acc[nb][8 * u + j];
                 if constexpr (MODE == 0) {
-                    out[((long)t * P + p) * N + n] = val;
+                    out[((long)t * P + p) * ldout + n] = val;
                 } else if constexpr (MODE == 4) {
-                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
+                    out[((long)t * P + p) * ldout + n] = val > 0.f ? val : slope * val;
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
                     out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
                 } else {
-                    const long o = ((long)t * P + p) * N + n;
+                    const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
                 }
             }
@@ -1015,7 +1015,7 @@ template <int NBW, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ in, const f16* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ skip,
                                                       float* __restrict__ out, int T, int H, int Wd, int K, int N,
-                                                      int NBtot, float slope) {
+                                                      int NBtot, float slope, int ldin, int ldout) {
     constexpr int F = 2 * NBW;
     constexpr int SH = (F + 3) / 4;
     constexpr int TH = 8, TW = 16, HX = TW + 2, NQ = (TH + 2) * HX;   // 180 halo pixels
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             if (e < NE) {
                 const int q = e >> 2, c4 = e & 3;
                 const int yy = y0 + q / HX - 1, xx = x0 + q % HX - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) v = *(const f32x4*)(in + ((long)(t * H + yy) * Wd + xx) * K + 16 * s + 4 * c4);
+                if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) v = *(const f32x4*)(in + ((long)(t * H + yy) * Wd + xx) * ldin + 16 * s + 4 * c4);
             }
             bst[i] = v;
         }
@@ -1137,9 +1137,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                 if (n >= N) continue;
                 const float val = acc[nb][8 * u + j];
                 if constexpr (MODE == 0) {
-                    out[((long)t * P + p) * N + n] = val;
+                    out[((long)t * P + p) * ldout + n] = val;
                 } else if constexpr (MODE == 4) {
-                    out[((long)t * P + p) * N + n] = val > 0.f ? val : slope * val;
+                    out[((long)t * P + p) * ldout + n] = val > 0.f ? val : slope * val;
                 } else if constexpr (MODE == 1) {
                     const int oc = n * 4 + (y & 1) * 2 + (x & 1);
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
                     out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
                 } else {
-                    const long o = ((long)t * P + p) * N + n;
+                    const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
                 }
             }
@@ -1571,7 +1571,7 @@ hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, c
 
 template <int MODE>
 static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W, const float* bias,
-                                   const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB, float slope) {
+                                   const float* skip, float* out, int T, int H, int Wd, int K, int N, int NB, float slope, int ldin, int ldout) {
     const long waves = (long)T * (((long)H * Wd + 31) / 32);
     // row blocks per workgroup: the fewest passes over the pixel operand with at most 6 blocks in registers, split evenly
     // (NB = 4 ran as 3 + 1 before: the second pass re-read and re-converted every pixel for a third of the MFMA work)
@@ -1589,44 +1589,49 @@ static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W
         const long tiles = (long)T * ((H + 7) / 8) * ((Wd + 15) / 16);
         const dim3 tgrid((unsigned)tiles, (NB + NBW - 1) / NBW);
         switch (NBW) {
-            case 2: hipLaunchKernelGGL((k_conv3x3_tile<2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            case 3: hipLaunchKernelGGL((k_conv3x3_tile<3, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            case 4: hipLaunchKernelGGL((k_conv3x3_tile<4, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            default: hipLaunchKernelGGL((k_conv3x3_tile<6, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 2: hipLaunchKernelGGL((k_conv3x3_tile<2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 3: hipLaunchKernelGGL((k_conv3x3_tile<3, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 4: hipLaunchKernelGGL((k_conv3x3_tile<4, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            default: hipLaunchKernelGGL((k_conv3x3_tile<6, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
         }
         return hipGetLastError();
     }
     if (lds_env && NB >= 2) {      // every multi-block conv: weights through LDS
         switch (NBW) {
-            case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            case 4: hipLaunchKernelGGL((k_conv3x3_lds<4, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-            default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+            case 2: hipLaunchKernelGGL((k_conv3x3_lds<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 3: hipLaunchKernelGGL((k_conv3x3_lds<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 4: hipLaunchKernelGGL((k_conv3x3_lds<4, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            default: hipLaunchKernelGGL((k_conv3x3_lds<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
         }
         return hipGetLastError();
     }
     switch (NBW) {
-        case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-        case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-        case 3: hipLaunchKernelGGL((k_conv3x3<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
-        default: hipLaunchKernelGGL((k_conv3x3<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope); break;
+        case 1: hipLaunchKernelGGL((k_conv3x3<1, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<2, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<3, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+        default: hipLaunchKernelGGL((k_conv3x3<6, MODE>), grid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias, const float* skip,
-                          float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope) {
+                          float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope, int ldin, int ldout) {
     if (K % 16 != 0 || NB * 32 < N) return hipErrorInvalidValue;
+    // ldin / ldout: floats per pixel of the input / of the output and skip tensors (0 = K / N): a convolution can read the first K
+    // channels of a wider pixel and write N channels into a slice of one (dense blocks, RRDBNet); float4 loads need ldin % 4 == 0
+    if (ldin == 0) ldin = K;
+    if (ldout == 0) ldout = N;
+    if (ldin < K || (ldin & 3) || ldout < N || ((mode == 1 || mode == 2) && ldout != N)) return hipErrorInvalidValue;
     if (mode == 1 && ((H | Wd) & 1)) return hipErrorInvalidValue;
     if (mode == 2 && (N & 3)) return hipErrorInvalidValue;
     if (mode == 3 && skip == nullptr) return hipErrorInvalidValue;
     const f16* Wh = (const f16*)W;
     switch (mode) {
-        case 0: return conv3x3_dispatch<0>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
-        case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
-        case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
-        case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
-        case 4: return conv3x3_dispatch<4>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope);
+        case 0: return conv3x3_dispatch<0>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+        case 1: return conv3x3_dispatch<1>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+        case 2: return conv3x3_dispatch<2>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+        case 3: return conv3x3_dispatch<3>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+        case 4: return conv3x3_dispatch<4>(st, in, Wh, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
         default: return hipErrorInvalidValue;
     }
 }

@@ -61,7 +61,7 @@ using ira_rt::Blk; using ira_rt::Prof; using ira_rt::SBlk; using ira_rt::SConv; 
 
 struct ira_model {
     int device = -1;
-    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR, 4 MPRNet
+    int arch = 0;                    // 0 Restormer, 1 NAFNet, 2 DnCNN, 3 SwinIR, 4 MPRNet, 5 RRDBNet
     ira_restormer_config cfg{};
     bool xr = false;                 // arch 0 with X-Restormer blocks
     int xr_spatial_heads[4] = {0, 0, 0, 0};
@@ -71,6 +71,7 @@ struct ira_model {
     ira_dncnn_config dcfg{};
     ira_swinir_config scfg{};
     ira_mprnet_config mcfg{};
+    ira_rrdbnet_config rcfg{};
     std::vector<std::vector<SBlk>> sw_blocks;
     std::vector<SConv> sw_lconv;
     SConv sw_cab;
@@ -152,6 +153,10 @@ inline int gfail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int up32(int n) { return (n + 31) / 32 * 32; }
+// output pixels per input pixel along each axis (SR models)
+inline int model_scale(const ira_model* m) {
+    return m->arch == 3 ? m->scfg.upscale : (m->arch == 5 ? m->rcfg.scale : (m->xr ? m->xr_scale : 1));
+}
 inline size_t al256(size_t n) { return (n + 255) / 256 * 256; }
 
 // ---- profiling wrapper: run one launch, optionally bracketed by events
@@ -207,6 +212,8 @@ bool dn_bind_weights(ira_model* m);
 int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool sw_bind_weights(ira_model* m);
 int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
+bool rr_bind_weights(ira_model* m);
+int rr_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool mpr_bind_weights(ira_model* m);
 int mpr_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 

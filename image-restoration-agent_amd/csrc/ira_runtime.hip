@@ -25,6 +25,7 @@ using namespace ira_rt;
 namespace {
 
 int forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out) {
+    if (m->arch == 5) return rr_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 4) return mpr_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 3) return sw_forward_enqueue(m, in, T, H, W, out);
     if (m->arch == 2) return dn_forward_enqueue(m, in, T, H, W, out);
@@ -294,6 +295,28 @@ int ira_dncnn_create(int device, const ira_dncnn_config* cfg, const void* blob, 
     return IRA_OK;
 }
 
+int ira_rrdbnet_create(int device, const ira_rrdbnet_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
+    if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_rrdbnet_create: NULL argument");
+    *out = nullptr;
+    if (cfg->scale != 1 && cfg->scale != 2 && cfg->scale != 4) return gfail(IRA_ERR_ARG, "scale must be 1, 2 or 4 (rrdbnet.py:146-159), got %d", cfg->scale);
+    if (cfg->num_in_ch < 1 || cfg->num_in_ch > 4 || cfg->num_out_ch < 1 || cfg->num_out_ch > 4 || cfg->num_in_ch != cfg->num_out_ch)
+        return gfail(IRA_ERR_ARG, "num_in_ch = num_out_ch in 1..4, got %d / %d", cfg->num_in_ch, cfg->num_out_ch);
+    if (cfg->num_feat < 16 || cfg->num_feat % 32 || cfg->num_grow_ch < 16 || cfg->num_grow_ch % 32 || cfg->num_block < 1)
+        return gfail(IRA_ERR_ARG, "num_feat=%d and num_grow_ch=%d must be multiples of 32, num_block=%d >= 1", cfg->num_feat, cfg->num_grow_ch, cfg->num_block);
+    ira_model* m = nullptr;
+    int rc = create_common(device, blob, bytes, &m);
+    if (rc != IRA_OK) return rc;
+    m->arch = 5; m->rcfg = *cfg;
+    m->cfg.inp_channels = m->cfg.out_channels = cfg->num_in_ch;
+    if (!rr_bind_weights(m)) {
+        g_err = m->err.empty() ? "weight blob: missing entries" : m->err;
+        ira_model_destroy(m);
+        return IRA_ERR_WEIGHTS;
+    }
+    *out = m;
+    return IRA_OK;
+}
+
 int ira_mprnet_create(int device, const ira_mprnet_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
     if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_mprnet_create: NULL argument");
     *out = nullptr;
@@ -434,7 +457,7 @@ int ira_forward(ira_model_t* m, const float* in, int B, int C, int H, int W, flo
     if (B <= 0 || H <= 0 || W <= 0 || (m->arch == 0 && ((H & 7) || (W & 7))))
         return m->fail(IRA_ERR_ARG, "ira_forward: B=%d H=%d W=%d (H, W multiples of 8)", B, H, W);
     const size_t n = (size_t)B * C * H * W;
-    const int s = m->arch == 3 ? m->scfg.upscale : (m->xr ? m->xr_scale : 1);   // SR models: the output is (B, C, H*s, W*s)
+    const int s = model_scale(m);   // SR models: the output is (B, C, H*s, W*s)
     const size_t no = n * s * s;
     int rc = ensure_scratch(m, al256(n * 4) + 2 * al256(no * 4));
     if (rc != IRA_OK) return rc;
@@ -565,7 +588,7 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
             if ((kv.first.first & 7) || (kv.first.second & 7))
                 return m->fail(IRA_ERR_ARG, "tile %dx%d is not a multiple of 8: choose tile_size, tile_pad, padding_size as multiples of 8",
                                kv.first.first, kv.first.second);
-    const int sc = m->arch == 3 ? m->scfg.upscale : (m->xr ? m->xr_scale : 1);      // tile_process with scale (:72-76,117-133)
+    const int sc = model_scale(m);      // tile_process with scale (:72-76,117-133)
     const size_t fbytes = (size_t)h * w * c, obytes = fbytes * sc * sc;
     uint8_t *fin = nullptr, *fout = nullptr; float *tin = nullptr, *tout = nullptr; int* ddev = nullptr;
     auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tin) hipFree(tin); if (tout) hipFree(tout); if (ddev) hipFree(ddev); };

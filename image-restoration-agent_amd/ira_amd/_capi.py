@@ -61,6 +61,11 @@ class IraMprnetConfig(C.Structure):
                 ('scale_orsnetfeats', C.c_int32), ('num_cab', C.c_int32), ('reduction', C.c_int32), ('prelu', C.c_float)]
 
 
+class IraRrdbnetConfig(C.Structure):
+    _fields_ = [('num_in_ch', C.c_int32), ('num_out_ch', C.c_int32), ('scale', C.c_int32), ('num_feat', C.c_int32), ('num_block', C.c_int32),
+                ('num_grow_ch', C.c_int32)]
+
+
 STRIP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
 
 
@@ -82,6 +87,7 @@ SIGNATURES = {
     'ira_dncnn_create': (_i, [_i, C.POINTER(IraDncnnConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_swinir_create': (_i, [_i, C.POINTER(IraSwinirConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_mprnet_create': (_i, [_i, C.POINTER(IraMprnetConfig), _vp, _sz, C.POINTER(_vp)]),
+    'ira_rrdbnet_create': (_i, [_i, C.POINTER(IraRrdbnetConfig), _vp, _sz, C.POINTER(_vp)]),
     'ira_model_destroy': (_i, [_vp]),
     'ira_last_error': (C.c_char_p, [_vp]),
     'ira_sync': (_i, [_vp]),

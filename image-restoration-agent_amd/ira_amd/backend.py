@@ -225,6 +225,18 @@ class MPRNetBackend(_Backend):
                      'ira_mprnet_create')
 
 
+class RRDBNetBackend(_Backend):
+    """One RRDBNet (Real-ESRGAN generator) on one MI355X (DiffBIR/utils/realesrgan/rrdbnet.py).  ``forward``: float32
+    (B,C,H,W) -> (B,C,H*scale,W*scale).  ``restore_padcrop(img, tile_size, tile_pad, padding_size=mod_scale)``: the tensor path of
+    RealESRGANer (realesrganer.py:71-183) on uint8 images."""
+
+    def __init__(self, cfg, state_dict, device: int = 0):
+        from .rrdbnet import pack_rrdbnet_blob, rrdbnet_cfg_struct
+        self.cfg = cfg
+        self.scale = cfg.scale
+        self._create(device, 'ira_rrdbnet_create', rrdbnet_cfg_struct(cfg), pack_rrdbnet_blob(state_dict, cfg), 'ira_rrdbnet_create')
+
+
 class SwinIRBackend(_Backend):
     """One SwinIR on one MI355X (SwinIR/models/network_swinir.py).  ``forward``: float32 (B,C,H,W) ->
     (B,C,H*upscale,W*upscale), any H, W.  ``restore``: the reference harness (SwinIR/inference.py:69-90,294-322: always-pad by

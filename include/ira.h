@@ -119,6 +119,14 @@ typedef struct ira_mprnet_config {
     float   prelu;
 } ira_mprnet_config;
 
+/* Constructor arguments of the reference RRDBNet, the Real-ESRGAN generator (DiffBIR/utils/realesrgan/rrdbnet.py:146; built with
+ * 3, 3, scale, 64, 23, 32 by set_realesrgan, realesrganer.py:321-328). */
+typedef struct ira_rrdbnet_config {
+    int32_t num_in_ch, num_out_ch;
+    int32_t scale;                                    /* 4, or 2 / 1 with a pixel-unshuffle of the input (:167-172) */
+    int32_t num_feat, num_block, num_grow_ch;         /* 64, 23, 32 */
+} ira_rrdbnet_config;
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible gfx950 devices. replaces torch.cuda.is_available() (demo.py:98). */
@@ -154,6 +162,12 @@ int ira_swinir_create(int device, const ira_swinir_config* cfg,
  * replaces: load_file("MPRNet.py").MPRNet(); utils.load_checkpoint; model.cuda().eval()  (MPRNet/demo.py:57-62). */
 int ira_mprnet_create(int device, const ira_mprnet_config* cfg,
                       const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
+/* RRDBNet: blob from ira_amd/rrdbnet.py::pack_rrdbnet_blob.  ira_forward(_device): (B, C, H, W) -> (B, C, H*scale, W*scale), H and W
+ * multiples of 2 (scale 2) / 4 (scale 1).  The tiler of RealESRGANer (realesrganer.py:71-183: mod-pad by reflection, tile_process with
+ * tile_pad, crop) is ira_restore_padcrop_u8 with padding_size = 2 / 4 / 1.
+ * replaces: RRDBNet(...); load_state_dict(loadnet['params_ema' | 'params']); eval  (realesrganer.py:321-328,53-69). */
+int ira_rrdbnet_create(int device, const ira_rrdbnet_config* cfg,
+                       const void* weight_blob, size_t weight_blob_bytes, ira_model_t** out_model);
 int ira_model_destroy(ira_model_t* model);
 
 /* Text of the last error on this handle (or, with model == NULL, of the last failed call that had
