@@ -346,7 +346,7 @@ def main_swinir(args):
         dist.destroy_process_group()
 
 
-def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_forward, cpu_name, crop=128):
+def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_forward, cpu_name, crop=128, scale=1):
     """One (1, H, W, 3) float32 NHWC frame resident in HBM through a whole-image network, output in HBM.  N > 1: independent replicas.
     make_backend(local_rank) -> backend; cpu_forward(x_nchw_cpu) = the oracle forward (cpu_baseline leg only)."""
     import torch
@@ -364,7 +364,7 @@ def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_fo
     be = make_backend(local_rank)
     _, noisy = synthetic_noisy_image(H, W, 3, sigma=25.0, seed=rank)
     x = torch.from_numpy(noisy).float().div(255.).unsqueeze(0).contiguous().to(dev)
-    y = torch.empty_like(x)
+    y = torch.empty((1, H * scale, W * scale, 3), dtype=torch.float32, device=dev)
 
     def barrier():
         if world > 1:
@@ -390,7 +390,7 @@ def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_fo
             dist.destroy_process_group()
         return
     step_s = elapsed / args.steps
-    result = {'metric': metric, 'value': round(world * H * W / 1e6 / step_s, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps,
+    result = {'metric': metric, 'value': round(world * H * W * scale * scale / 1e6 / step_s, 3), 'unit': 'MP/s', 'n_gpus': world, 'steps': args.steps,
               'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
               'dtype': dtype, 'data': 'synthetic', 'config': {'workload': workload + f', (1, {H}, {W}, 3) float32 per GPU per step'}}
     if world == 1 and not args.no_kernel_profile:
@@ -423,7 +423,7 @@ def _whole_image_bench(args, make_backend, H, W, metric, workload, dtype, cpu_fo
             for _ in range(reps):
                 cpu_forward(xc)
             dt = (time.perf_counter() - t1) / reps
-        result['cpu_baseline'] = {'value': round(crop * crop / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+        result['cpu_baseline'] = {'value': round(crop * crop * scale * scale / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
                                   'sample': f'{cpu_name} (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {crop}x{crop} crop after 1 warm-up ({dt:.2f} s each)'}
     print(json.dumps(result), flush=True)
     be.close()
@@ -449,6 +449,26 @@ def main_xrestormer(args):
         'restored megapixels/sec (X-Restormer, 1280x720 frame padded to 768 rows, whole image)',
         'X-Restormer dim 48, blocks [2,4,4,4]+4, channel/spatial heads [1,2,4,8] (26.0M params, seeded weights)',
         'f16 storage / f32 accumulate + f32 residual stream', cpu_forward, 'oracle/xrestormer_oracle.py')
+
+
+def main_realesrgan(args):
+    """RRDBNet / Real-ESRGAN x4plus (23 RRDB blocks, 16.7M parameters): one 960x540 frame -> 3840x2160, whole image
+    (the shape of the SwinIR workload)."""
+    import torch
+    from ira_amd.backend import RRDBNetBackend
+    from ira_amd.rrdbnet import realesrgan_config, seeded_state_dict
+    cfg = realesrgan_config(4)
+
+    def cpu_forward(xc):
+        from oracle.rrdbnet_oracle import rrdbnet_forward
+        if not hasattr(cpu_forward, 'sd'):
+            cpu_forward.sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(cfg, 0).items()}
+        return rrdbnet_forward(xc, cpu_forward.sd, cfg.to_dict())
+    return _whole_image_bench(
+        args, lambda lr: RRDBNetBackend(cfg, seeded_state_dict(cfg, 0), device=lr), 540, 960,
+        'restored output megapixels/sec (Real-ESRGAN x4 RRDBNet, 960x540 -> 3840x2160, whole image)',
+        'RRDBNet 64 feat / 23 blocks / 32 grow, scale 4 (16.7M params, seeded weights)',
+        'f32 streams, f16 hi+lo MFMA operands, f32 accumulate', cpu_forward, 'oracle/rrdbnet_oracle.py', crop=64, scale=4)
 
 
 def main_mprnet(args):
@@ -556,7 +576,7 @@ def main_agent_chain(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'restormer4k_whole', 'nafnet512', 'swinir_x4', 'xrestormer720p', 'mprnet720p', 'agent_chain'],
+    ap.add_argument('--workload', default='restormer4k', choices=['restormer4k', 'restormer4k_whole', 'nafnet512', 'swinir_x4', 'xrestormer720p', 'mprnet720p', 'realesrgan_x4', 'agent_chain'],
                     help='restormer4k = the headline metric (BASELINE configs[2]); nafnet512 = configs[1]; swinir_x4 = configs[3]')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -580,6 +600,8 @@ def main():
         return main_xrestormer(args)
     if args.workload == 'mprnet720p':
         return main_mprnet(args)
+    if args.workload == 'realesrgan_x4':
+        return main_realesrgan(args)
     if args.workload == 'agent_chain':
         return main_agent_chain(args)
 

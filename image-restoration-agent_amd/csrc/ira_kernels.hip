@@ -1011,14 +1011,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
 // split ONCE into LDS ([plane][k half][pixel] x 16 B: a wave's B fragment of any tap is 2 runs of 16 consecutive 16-byte slots,
 // conflict-free), loaded a k-step ahead of its use; the nine taps then read their fragments at shifted tile offsets.  Same
 // operands, same MFMA order as k_conv3x3_lds: bitwise the same output.
-template <int NBW, int MODE>
+template <int NBW, int PG, int MODE>
 __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ in, const f16* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ skip,
                                                       float* __restrict__ out, int T, int H, int Wd, int K, int N,
                                                       int NBtot, float slope, int ldin, int ldout) {
     constexpr int F = 2 * NBW;
     constexpr int SH = (F + 3) / 4;
-    constexpr int TH = 8, TW = 16, HX = TW + 2, NQ = (TH + 2) * HX;   // 180 halo pixels
+    constexpr int TH = 8 * PG, TW = 16, HX = TW + 2, NQ = (TH + 2) * HX;   // PG pixel groups per wave: rows 2w, 2w + 1 of each 8-row band
     constexpr int NE = NQ * 4, BI = (NE + 255) / 256;                  // float4 elements of one k-step of the halo tile
     __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
     __shared__ __attribute__((aligned(16))) half8 bt[2][2][2][NQ];    // [buffer][plane hi / lo][k half][halo pixel]
@@ -1029,24 +1029,25 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
     const int trem = (int)(tile - (long)t * tiles_y * tiles_x);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
     const int py = 2 * wave + (r >> 4), pxx = r & 15;
-    const int y = y0 + py, x = x0 + pxx;
-    const bool valid = y < H && x < Wd;
-    const int P = H * Wd, p = y * Wd + x;
+    const int x = x0 + pxx;
+    const int P = H * Wd;
     const int nb0 = blockIdx.y * NBW;
 
-    f32x16 acc[NBW];
+    f32x16 acc[PG][NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        acc[nb] = zero16();
+        acc[0][nb] = zero16();
         if (bias != nullptr) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
-                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                    acc[0][nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
                 }
         }
+#pragma unroll
+        for (int g = 1; g < PG; ++g) acc[g][nb] = acc[0][nb];
     }
     const int KT = K >> 4;
     const int nsteps = 9 * KT;
@@ -1107,15 +1108,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                 for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(step + 1, wave + 4 * i);
             }
             const int q = (py + tap / 3) * HX + pxx + tap % 3;
-            const half8 b = bt[bb][0][h][q], bl = bt[bb][1][h][q];
+            half8 b[PG], bl[PG];
+#pragma unroll
+            for (int g = 0; g < PG; ++g) { b[g] = bt[bb][0][h][q + 8 * g * HX]; bl[g] = bt[bb][1][h][q + 8 * g * HX]; }
             const int cur = step & 1;
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 if (nb0 + nb < NBtot) {
                     const half8 a = wl[cur][nb][lane], al = wl[cur][NBW + nb][lane];
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < PG; ++g) {
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl[g], acc[g][nb], 0, 0, 0);
+                    }
                 }
             }
             if (step + 1 < nsteps) {
@@ -1126,7 +1132,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             __syncthreads();
         }
     }
-    if (!valid) return;
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+    const int y = y0 + py + 8 * g;
+    if (!(y < H && x < Wd)) continue;
+    const int p = y * Wd + x;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -1135,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             for (int j = 0; j < 8; ++j) {
                 const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
                 if (n >= N) continue;
-                const float val = acc[nb][8 * u + j];
+                const float val = acc[g][nb][8 * u + j];
                 if constexpr (MODE == 0) {
                     out[((long)t * P + p) * ldout + n] = val;
                 } else if constexpr (MODE == 4) {
@@ -1151,6 +1161,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                     out[o] = val + skip[o];
                 }
             }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1585,14 +1596,25 @@ static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W
     // barriers: measured faster for >= 3 row blocks and K >= 96 (MPRNet CABs, Restormer up-convolutions), slower for the 64-channel
     // SwinIR upsampler and the 2-block convolutions
     static const int tile_min_nbw = env_int("IRA_CONV_TILE_MINNBW", 3), tile_min_kt = env_int("IRA_CONV_TILE_MINKT", 6);
-    if (tile_env && lds_env && NBW >= tile_min_nbw && (K >> 4) >= tile_min_kt) {
-        const long tiles = (long)T * ((H + 7) / 8) * ((Wd + 15) / 16);
+    static const int tile_small = env_int("IRA_CONV_TILE_SMALL", 1);     // 1-2 row blocks: 2 pixel groups per wave
+    const bool big = NBW >= tile_min_nbw && (K >> 4) >= tile_min_kt, small = tile_small && NBW <= 2 && (K >> 4) >= 4;
+    if (tile_env && lds_env && (big || small)) {
+        static const int pg34 = env_int("IRA_CONV_TILE_PG34", 1);
+        const int pg = NBW <= 2 ? 2 : ((NBW == 3 || NBW == 4) ? pg34 : 1);
+        const long tiles = (long)T * ((H + 8 * pg - 1) / (8 * pg)) * ((Wd + 15) / 16);
         const dim3 tgrid((unsigned)tiles, (NB + NBW - 1) / NBW);
         switch (NBW) {
-            case 2: hipLaunchKernelGGL((k_conv3x3_tile<2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
-            case 3: hipLaunchKernelGGL((k_conv3x3_tile<3, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
-            case 4: hipLaunchKernelGGL((k_conv3x3_tile<4, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
-            default: hipLaunchKernelGGL((k_conv3x3_tile<6, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 1: hipLaunchKernelGGL((k_conv3x3_tile<1, 2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 2: hipLaunchKernelGGL((k_conv3x3_tile<2, 2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
+            case 3:
+                if (pg == 2) hipLaunchKernelGGL((k_conv3x3_tile<3, 2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+                else hipLaunchKernelGGL((k_conv3x3_tile<3, 1, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+                break;
+            case 4:
+                if (pg == 2) hipLaunchKernelGGL((k_conv3x3_tile<4, 2, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+                else hipLaunchKernelGGL((k_conv3x3_tile<4, 1, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout);
+                break;
+            default: hipLaunchKernelGGL((k_conv3x3_tile<6, 1, MODE>), tgrid, block, 0, st, in, W, bias, skip, out, T, H, Wd, K, N, NB, slope, ldin, ldout); break;
         }
         return hipGetLastError();
     }
