@@ -22,9 +22,10 @@ static int gram_splits(int T, int heads, long nblk) {
     // in its launch-batch, and the partials are reduced in fixed order (bitwise reproducible)
     (void)T; (void)heads;
     const long nsteps = (nblk + 3) / 4;
-    // at least 64 steps per split, at most 512 splits: a 512x512 tile gets 128, a whole 720p image 480 (with the old cap of 64 a
-    // lone image ran 480 dependent load+MFMA steps per wave: 642 us per launch at C = 96)
-    return (int)std::max(1L, std::min(nsteps / 64, 512L));
+    // at least 64 steps per split, at most 2048 splits: a 512x512 tile gets 128, a whole 720p image 480, an untiled 4K frame 2048
+    // (with a cap of 512 its waves ran 506 dependent load+MFMA steps each: Gram 9.4 % of the 249 ms frame, 5.2 % of 243 ms now;
+    // with the first cap of 64 a lone 720p image took 642 us per launch at C = 96)
+    return (int)std::max(1L, std::min(nsteps / 64, 2048L));
 }
 
 static bool load_block(ira_model* m, const std::string& p, int C, int heads, int Hp, int level, Blk& b) {
