@@ -1049,6 +1049,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
 #pragma unroll
         for (int g = 1; g < PG; ++g) acc[g][nb] = acc[0][nb];
     }
+    // The accumulators were just filled by global loads (bias).  Without an explicit wait here the compiler's wait-count
+    // analysis carries "accumulators may be pending" around the loop's back edge and puts s_waitcnt vmcnt(0) in front of
+    // the first MFMA of EVERY step: each step then waited for the weight fragments it had just requested for the NEXT
+    // step (a full L2 round trip per 12 MFMAs; SQ counters: MFMA pipe 37 % busy, waves 39 % in s_waitcnt).
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
     const int KT = K >> 4;
     const int nsteps = 9 * KT;
     const long lo_off = 9L * NBtot * KT * 512;
@@ -1088,12 +1093,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             }
         }
     };
-    half8 stg[SH];
+    // weight fragments travel global -> registers -> LDS TWO steps ahead of their use: one step of MFMAs (~400 cycles) is shorter
+    // than an L2 round trip, so with a one-step distance the ds_write at the end of every step waited for the loads of its start
+    half8 nxt[SH], ld[SH];
 #pragma unroll
-    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(0, wave + 4 * i);
+    for (int i = 0; i < SH; ++i) if ((F % 4 == 0) || wave + 4 * i < F) ld[i] = *gsrc(0, wave + 4 * i);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) if ((F % 4 == 0) || wave + 4 * i < F) nxt[i] = *gsrc(nsteps > 1 ? 1 : 0, wave + 4 * i);
     bload(0);
 #pragma unroll
-    for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[0][wave + 4 * i][lane] = stg[i];
+    for (int i = 0; i < SH; ++i) if ((F % 4 == 0) || wave + 4 * i < F) wl[0][wave + 4 * i][lane] = ld[i];
     bstore(0);
     __syncthreads();
 
@@ -1103,9 +1112,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int step = 9 * s + tap;
-            if (step + 1 < nsteps) {
+            if (step + 2 < nsteps) {
 #pragma unroll
-                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) stg[i] = *gsrc(step + 1, wave + 4 * i);
+                for (int i = 0; i < SH; ++i) if ((F % 4 == 0) || wave + 4 * i < F) ld[i] = *gsrc(step + 2, wave + 4 * i);
             }
             const int q = (py + tap / 3) * HX + pxx + tap % 3;
             half8 b[PG], bl[PG];
@@ -1113,21 +1122,21 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             for (int g = 0; g < PG; ++g) { b[g] = bt[bb][0][h][q + 8 * g * HX]; bl[g] = bt[bb][1][h][q + 8 * g * HX]; }
             const int cur = step & 1;
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-                if (nb0 + nb < NBtot) {
-                    const half8 a = wl[cur][nb][lane], al = wl[cur][NBW + nb][lane];
+            for (int nb = 0; nb < NBW; ++nb) {       // row blocks past NBtot (partial last chunk) compute on a clamped copy, never stored:
+                const half8 a = wl[cur][nb][lane], al = wl[cur][NBW + nb][lane];   // no branch in the loop, so reads and MFMAs interleave
 #pragma unroll
-                    for (int g = 0; g < PG; ++g) {
-                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
-                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
-                        acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl[g], acc[g][nb], 0, 0, 0);
-                    }
+                for (int g = 0; g < PG; ++g) {
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl[g], acc[g][nb], 0, 0, 0);
                 }
             }
             if (step + 1 < nsteps) {
 #pragma unroll
-                for (int i = 0; i < SH; ++i) if (wave + 4 * i < F) wl[cur ^ 1][wave + 4 * i][lane] = stg[i];
+                for (int i = 0; i < SH; ++i) if ((F % 4 == 0) || wave + 4 * i < F) wl[cur ^ 1][wave + 4 * i][lane] = nxt[i];
             }
+#pragma unroll
+            for (int i = 0; i < SH; ++i) nxt[i] = ld[i];
             if (tap == 8 && s + 1 < KT) bstore(bb ^ 1);
             __syncthreads();
         }
