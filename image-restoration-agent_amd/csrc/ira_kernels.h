@@ -76,6 +76,10 @@ hipError_t launch_nhwc_to_nchw(hipStream_t st, const float* in, float* out, int 
 hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
                          const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg,
                          const float* scale = nullptr);   // inmode 4: fp16 x scaled by scale[t][k] (fp32 [T][K])
+// the same contraction with both operands through LDS (k_pw_gemm); bitwise equal to k_naf_pw / k_pw_nres_lds on their common cases
+bool pw_gemm_supported(int K, int N, int NBtot);
+hipError_t launch_pw_gemm(hipStream_t st, const void* x, bool x_f32, int K, const void* W, long w_tile_stride, const float* bias,
+                          const float* resid, float* y, int N, int NBtot, int T, int P);
 int naf_dw_sg_blocks(int H, int W, int c);      // partial-sum records per image written by launch_naf_dw_sg
 hipError_t launch_naf_dw_sg(hipStream_t st, const void* in, const float* w, const float* bias, void* out, float* part,
                             int T, int H, int W, int c);

@@ -16,6 +16,8 @@
 #include "ira_kernels.h"
 #include "ira_device.h"
 
+#include <cstdlib>
+
 namespace ira {
 
 namespace {
@@ -161,6 +163,133 @@ __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, in
                     const int q = n0 / Nq, cc = n0 - q * Nq;
                     dst = (((long)t * 2 * Hg + 2 * Y + (q >> 1)) * (2 * Wg) + 2 * X + (q & 1)) * Nq + cc;
                 }
+                if (resid != nullptr) {
+                    lo += *(const f32x4*)(resid + dst);
+                    hi += *(const f32x4*)(resid + dst + 4);
+                }
+                *(f32x4*)(y + dst) = lo;
+                *(f32x4*)(y + dst + 4) = hi;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same contraction with BOTH operands staged through LDS in stages of 32 input channels (two k-steps), two stages ahead of
+// their use in registers.  k_naf_pw feeds its MFMAs with pixel fragments loaded from global memory by the wave that consumes
+// them; in that loop the compiler waits vmcnt(0) at the first use of every step, which also retires the weight loads just
+// issued for the next step: every step costs a memory round trip.  Here every MFMA operand comes from LDS (counted lgkmcnt
+// waits, reads interleaved with MFMAs), the only vmcnt waits are in front of the ds_writes and leave the newest stage's loads in
+// flight, one barrier covers 4 * NBW MFMAs per wave, and the pixel rows are read as 64 / 128 contiguous bytes.
+// IN_F32 = false: x fp16 [T][P][K]; true: x fp32 [T][P][K] rounded to fp16 (k_naf_pw's IN_F32).  y fp32 [T][P][N] = acc (+ resid).
+// Same operands and MFMA order per accumulator as k_naf_pw: bitwise the same output.
+template <int NBW, bool XF32>
+__global__ __launch_bounds__(256) void k_pw_gemm(const void* __restrict__ xin, int K, const f16* __restrict__ W, long w_tile_stride,
+                                                 const float* __restrict__ bias, const float* resid, float* y, int N, int NBtot,
+                                                 int T, int P) {
+    constexpr int F = 2 * NBW;                    // fragments per k-step: NBW hi + NBW lo
+    constexpr int FS = 2 * F;                     // per stage (2 k-steps)
+    constexpr int SHA = (FS + 3) / 4;             // weight fragments staged per wave
+    __shared__ __attribute__((aligned(16))) half8 wl[2][FS][64];
+    __shared__ __attribute__((aligned(16))) half8 bl[2][2][2][128];     // [buffer][k-step][k half][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int chunks = (P + 127) >> 7;
+    const int t = blockIdx.x / chunks;
+    const int p0 = (blockIdx.x % chunks) * 128;
+    const int nb0 = blockIdx.y * NBW;
+    const int pl = 32 * wave + r;                 // this lane's pixel within the tile
+    const bool valid = p0 + pl < P;
+    const long px = (long)t * P + (valid ? p0 + pl : P - 1);
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        acc[nb] = zero16();
+        if (bias != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * (nb0 + nb) + 16 * u + 8 * h + j;
+                    acc[nb][8 * u + j] = (n < N) ? bias[n] : 0.f;
+                }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the bias loads retire here, not at the loop's first MFMA
+    const int KT = K >> 4, NS = KT >> 1;          // K % 32 == 0
+    const f16* wt = W + (long)t * w_tile_stride + lane * 8;
+    const long lo_off = (long)NBtot * KT * 512;
+    // weight fragment f of stage g: k-step 2g + f / F, within it f % F < NBW -> hi plane block nb0 + f % F, else lo plane
+    auto wsrc = [&](int g, int f) -> const half8* {
+        const int s = 2 * g + f / F, ff = f % F;
+        int nb = nb0 + (ff < NBW ? ff : ff - NBW);
+        if (nb >= NBtot) nb = NBtot - 1;
+        return (const half8*)(wt + (ff < NBW ? 0 : lo_off) + ((long)nb * KT + s) * 512);
+    };
+    // pixel element e = tid + 256 i (i < 2): pixel e / 4, 8-channel part e % 4 of the stage's 32 channels
+    auto bsrc = [&](int g, int i) -> half8 {
+        const int e = tid + 256 * i, q = e >> 2, part = e & 3;
+        const int pp = p0 + q < P ? p0 + q : P - 1;
+        const long off = ((long)t * P + pp) * K + 32 * g + 8 * part;
+        if constexpr (XF32) {
+            const float* src = (const float*)xin + off;
+            return cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else {
+            return *(const half8*)((const f16*)xin + off);
+        }
+    };
+    half8 wa[SHA], wb[SHA], ba[2], bb[2];         // stage + 1 (a) and stage + 2 (b) in registers
+    auto wload = [&](int g, half8 (&dst)[SHA]) {
+#pragma unroll
+        for (int i = 0; i < SHA; ++i) if ((FS % 4 == 0) || wave + 4 * i < FS) dst[i] = *wsrc(g, wave + 4 * i);
+    };
+    auto store = [&](int buf, const half8 (&wsrc_)[SHA], const half8 (&bsrc_)[2]) {
+#pragma unroll
+        for (int i = 0; i < SHA; ++i) if ((FS % 4 == 0) || wave + 4 * i < FS) wl[buf][wave + 4 * i][lane] = wsrc_[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, q = e >> 2, part = e & 3;
+            bl[buf][part >> 1][part & 1][q] = bsrc_[i];
+        }
+    };
+    wload(0, wb);
+    bb[0] = bsrc(0, 0); bb[1] = bsrc(0, 1);
+    wload(NS > 1 ? 1 : 0, wa);
+    ba[0] = bsrc(NS > 1 ? 1 : 0, 0); ba[1] = bsrc(NS > 1 ? 1 : 0, 1);
+    store(0, wb, bb);
+    __syncthreads();
+    for (int g = 0; g < NS; ++g) {
+        const int cur = g & 1;
+        if (g + 2 < NS) {
+            wload(g + 2, wb);
+            bb[0] = bsrc(g + 2, 0); bb[1] = bsrc(g + 2, 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 b = bl[cur][ks][h][pl];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const half8 a = wl[cur][ks * F + nb][lane], al = wl[cur][ks * F + NBW + nb][lane];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nb], 0, 0, 0);
+            }
+        }
+        if (g + 1 < NS) store(cur ^ 1, wa, ba);
+#pragma unroll
+        for (int i = 0; i < SHA; ++i) wa[i] = wb[i];
+        ba[0] = bb[0]; ba[1] = bb[1];
+        __syncthreads();
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n0 = 32 * (nb0 + nb) + 16 * u + 8 * h;
+            if (n0 + 8 <= N) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = acc[nb][8 * u + j]; hi[j] = acc[nb][8 * u + 4 + j]; }
+                const long dst = px * N + n0;
                 if (resid != nullptr) {
                     lo += *(const f32x4*)(resid + dst);
                     hi += *(const f32x4*)(resid + dst + 4);
@@ -487,10 +616,37 @@ static hipError_t naf_pw_nbw(hipStream_t st, const void* x, int K, const f16* W,
     return naf_pw_launch<1, INMODE, OUTMODE>(st, x, K, W, wts, bias, resid, y, N, NBtot, T, Hg, Wg, scale);
 }
 
+bool pw_gemm_supported(int K, int N, int NBtot) {
+    static const int gemm_env = getenv("IRA_PW_GEMM") ? atoi(getenv("IRA_PW_GEMM")) : 1;
+    return gemm_env && K > 0 && K % 32 == 0 && N % 8 == 0 && NBtot * 32 >= N;
+}
+
+// y fp32 [T][P][N] = W x (+ bias) (+ resid): x fp16 or fp32 [T][P][K]; W fragment-major hi + lo planes, w_tile_stride halfs per image
+hipError_t launch_pw_gemm(hipStream_t st, const void* x, bool x_f32, int K, const void* W, long w_tile_stride, const float* bias,
+                          const float* resid, float* y, int N, int NBtot, int T, int P) {
+    if (!pw_gemm_supported(K, N, NBtot) || T <= 0 || P <= 0) return hipErrorInvalidValue;
+    const int passes = (NBtot + 3) / 4, nbw = (NBtot + passes - 1) / passes;       // <= 4 row blocks per workgroup, split evenly
+    const dim3 grid((unsigned)((long)T * ((P + 127) / 128)), (unsigned)((NBtot + nbw - 1) / nbw)), block(256);
+    const f16* Wh = (const f16*)W;
+#define IRA_GEMM(NBW_) \
+    do { if (x_f32) hipLaunchKernelGGL((k_pw_gemm<NBW_, true>), grid, block, 0, st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, P); \
+         else hipLaunchKernelGGL((k_pw_gemm<NBW_, false>), grid, block, 0, st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, P); } while (0)
+    switch (nbw) {
+        case 1: IRA_GEMM(1); break;
+        case 2: IRA_GEMM(2); break;
+        case 3: IRA_GEMM(3); break;
+        default: IRA_GEMM(4); break;
+    }
+#undef IRA_GEMM
+    return hipGetLastError();
+}
+
 hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
                          const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg,
                          const float* scale) {
     if (inmode == IN_SCALED && scale == nullptr) return hipErrorInvalidValue;
+    if (outmode == OUT_RES && (inmode == IN_F16 || inmode == IN_F32) && pw_gemm_supported(K, N, NBtot) && T > 0 && Hg > 0 && Wg > 0)
+        return launch_pw_gemm(st, x, inmode == IN_F32, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg * Wg);
     if (K <= 0 || K % 16 != 0 || N % 8 != 0 || NBtot * 32 < N || T <= 0 || Hg <= 0 || Wg <= 0) return hipErrorInvalidValue;
     if ((inmode == IN_S2D || inmode == IN_S2DX2) && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
     if (outmode == OUT_SHUFFLE_ADD && (N % 32 != 0)) return hipErrorInvalidValue;  // N/4 channels, runs of 8
