@@ -11,6 +11,10 @@ in HBM.  N ranks share the tile list of the SAME frame (strong scaling: total wo
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definitions of every field).
+
+Other workloads (--workload): nafnet512 (BASELINE configs[1]), swinir_x4 (configs[3]), agent_chain (configs[4] without the LLM),
+xrestormer720p, mprnet720p, realesrgan_x4 (the "next" rows of SURVEY 8), restormer4k_whole (the untiled frame; N > 1: horizontal bands
+with halo-row and Gram exchange over RCCL).  IRA_DIST_BACKEND=gloo rehearses the N > 1 paths with every rank on one GPU (never a result).
 """
 import argparse
 import json
