@@ -641,12 +641,14 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
 // which is exactly the A/B fragment of v_mfma_f32_16x16x32_f16 (lane l: row/col l&15, k = 8(l>>4)+j).
 // One wave = (tile, head, split s): strides over the tile's 32-pixel steps s, s+S, ...
 // part: fp32 [T][S][heads][c*c + 2c]: gram[qi][kj], then sum q^2 [c], then sum k^2 [c].
-template <int CT>
+template <int CT, int PER>
 __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float* __restrict__ part, int T,
                                               int nblk, int C, int heads, int S, int bands) {
-    // bands (a divisor of CT): the q-channel tiles of one (tile, head, split) are shared out over `bands` waves.  Every output
-    // element still accumulates the same pixels in the same order, so the result does not depend on `bands`; the launcher
-    // uses it to fill the chip when there are few tiles (a whole 720p image at heads = 1 had 64 waves for 1024 SIMDs).
+    // bands = CT / PER: the q-channel tiles of one (tile, head, split) are shared out over `bands` waves, PER tiles each.  Every
+    // output element still accumulates the same pixels in the same order, so the result does not depend on `bands`; the launcher
+    // uses it to fill the chip when there are few tiles (a whole 720p image at heads = 1 had 64 waves for 1024 SIMDs).  PER is a
+    // template parameter so that a wave only holds the accumulators of its own rows: with the full CT x CT set (144 registers
+    // at c = 96) the banded waves of a 5-tile shard ran two per SIMD, and the step's load -> MFMA chain had nothing to hide behind.
     constexpr int c = CT * 16;
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     const long wv0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -656,64 +658,62 @@ __global__ __launch_bounds__(256) void k_gram(const f16* __restrict__ qk, float*
     const int s = (int)(wv % S);
     const int hd = (int)((wv / S) % heads);
     const int t = (int)(wv / ((long)S * heads));
-    const int per = CT / bands, i_lo = band * per, i_hi = i_lo + per;
+    const int i_lo = band * PER;
 
-    f32x4 acc[CT][CT];
-    float nq[CT], nk[CT];
+    f32x4 acc[PER][CT];
+    float nq[PER], nk[CT];
 #pragma unroll
-    for (int i = 0; i < CT; ++i) {
-        nq[i] = 0.f; nk[i] = 0.f;
+    for (int i = 0; i < PER; ++i) {
+        nq[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) nk[j] = 0.f;
     const int nsteps = (nblk + 3) >> 2;
     const f16* base = qk + (long)t * nblk * (2 * C) * 8;
     for (int step = s; step < nsteps; step += S) {
         const int blk = step * 4 + lg;
         const bool ok = blk < nblk;
         const f16* bp = base + ((long)(ok ? blk : 0) * (2 * C) + hd * c + li) * 8;
-        half8 a[CT], b[CT];
+        half8 a[PER], b[CT];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            a[i] = ok ? *(const half8*)(bp + (long)(16 * (i_lo + i)) * 8) : zero8();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float qa = (float)a[i][j]; nq[i] = fmaf(qa, qa, nq[i]); }
+        }
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const bool mine = i >= i_lo && i < i_hi;             // wave-uniform
-            a[i] = (ok && mine) ? *(const half8*)(bp + (long)(16 * i) * 8) : zero8();
             b[i] = ok ? *(const half8*)(bp + (long)(C + 16 * i) * 8) : zero8();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float qa = (float)a[i][j], kb = (float)b[i][j];
-                nq[i] = fmaf(qa, qa, nq[i]);
-                nk[i] = fmaf(kb, kb, nk[i]);
-            }
+            for (int j = 0; j < 8; ++j) { const float kb = (float)b[i][j]; nk[i] = fmaf(kb, kb, nk[i]); }
         }
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            if (i >= i_lo && i < i_hi) {
+        for (int i = 0; i < PER; ++i)
 #pragma unroll
-                for (int j = 0; j < CT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
+            for (int j = 0; j < CT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     float* dst = part + (((long)t * S + s) * heads + hd) * (c * c + 2 * c);
     // D layout 16x16: col = lane & 15 (k channel), row = 4*(lane>>4) + reg (q channel)
 #pragma unroll
-    for (int i = 0; i < CT; ++i) {
-        if (i >= i_lo && i < i_hi) {
+    for (int i = 0; i < PER; ++i)
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
+        for (int j = 0; j < CT; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(16 * i + 4 * lg + e) * c + 16 * j + li] = acc[i][j][e];
-        }
+            for (int e = 0; e < 4; ++e) dst[(16 * (i_lo + i) + 4 * lg + e) * c + 16 * j + li] = acc[i][j][e];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        float a = nq[i];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        if (lg == 0) dst[c * c + 16 * (i_lo + i) + li] = a;
     }
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        float a = nq[i], b = nk[i];
-        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        float b = nk[i];
         b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-        if (lg == 0) {
-            if (i >= i_lo && i < i_hi) dst[c * c + 16 * i + li] = a;
-            if (band == 0) dst[c * c + c + 16 * i + li] = b;
-        }
+        if (lg == 0 && band == 0) dst[c * c + c + 16 * i + li] = b;
     }
 }
 
@@ -1549,13 +1549,21 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
     const long waves = waves1 * bands;
     const dim3 grid(grid1d(waves, 4)), block(256);
     const f16* q = (const f16*)qk;
-    switch (CT) {
-        case 1: hipLaunchKernelGGL((k_gram<1>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
-        case 2: hipLaunchKernelGGL((k_gram<2>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
-        case 3: hipLaunchKernelGGL((k_gram<3>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
-        case 6: hipLaunchKernelGGL((k_gram<6>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands); break;
+#define IRA_GRAM(CT_, PER_) hipLaunchKernelGGL((k_gram<CT_, PER_>), grid, block, 0, st, q, part, T, nblk, C, heads, S, bands)
+    const int per = CT / bands;
+    switch (CT * 8 + per) {
+        case 1 * 8 + 1: IRA_GRAM(1, 1); break;
+        case 2 * 8 + 1: IRA_GRAM(2, 1); break;
+        case 2 * 8 + 2: IRA_GRAM(2, 2); break;
+        case 3 * 8 + 1: IRA_GRAM(3, 1); break;
+        case 3 * 8 + 3: IRA_GRAM(3, 3); break;
+        case 6 * 8 + 1: IRA_GRAM(6, 1); break;
+        case 6 * 8 + 2: IRA_GRAM(6, 2); break;
+        case 6 * 8 + 3: IRA_GRAM(6, 3); break;
+        case 6 * 8 + 6: IRA_GRAM(6, 6); break;
         default: return hipErrorInvalidValue;
     }
+#undef IRA_GRAM
     return hipGetLastError();
 }
 
