@@ -182,10 +182,10 @@ __global__ __launch_bounds__(256) void k_naf_pw(const void* __restrict__ xin, in
 // flight, one barrier covers 4 * NBW MFMAs per wave, and the pixel rows are read as 64 / 128 contiguous bytes.
 // IN_F32 = false: x fp16 [T][P][K]; true: x fp32 [T][P][K] rounded to fp16 (k_naf_pw's IN_F32).  y fp32 [T][P][N] = acc (+ resid).
 // Same operands and MFMA order per accumulator as k_naf_pw: bitwise the same output.
-template <int NBW, bool XF32>
+template <int NBW, int XMODE>   // XMODE: IN_F16, IN_F32, IN_GATED or IN_SCALED of k_naf_pw
 __global__ __launch_bounds__(256) void k_pw_gemm(const void* __restrict__ xin, int K, const f16* __restrict__ W, long w_tile_stride,
                                                  const float* __restrict__ bias, const float* resid, float* y, int N, int NBtot,
-                                                 int T, int P) {
+                                                 int T, int P, const float* __restrict__ scale) {
     constexpr int F = 2 * NBW;                    // fragments per k-step: NBW hi + NBW lo
     constexpr int FS = 2 * F;                     // per stage (2 k-steps)
     constexpr int SHA = (FS + 3) / 4;             // weight fragments staged per wave
@@ -229,10 +229,26 @@ __global__ __launch_bounds__(256) void k_pw_gemm(const void* __restrict__ xin, i
     auto bsrc = [&](int g, int i) -> half8 {
         const int e = tid + 256 * i, q = e >> 2, part = e & 3;
         const int pp = p0 + q < P ? p0 + q : P - 1;
-        const long off = ((long)t * P + pp) * K + 32 * g + 8 * part;
-        if constexpr (XF32) {
+        const int c0 = 32 * g + 8 * part;
+        const long off = ((long)t * P + pp) * K + c0;
+        if constexpr (XMODE == IN_F32) {
             const float* src = (const float*)xin + off;
             return cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
+        } else if constexpr (XMODE == IN_GATED) {
+            const f16* src = (const f16*)xin + ((long)t * P + pp) * 2 * K + c0;
+            const half8 a1 = *(const half8*)src, a2 = *(const half8*)(src + K);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a1[j] * (float)a2[j]);
+            return o;
+        } else if constexpr (XMODE == IN_SCALED) {
+            const half8 a = *(const half8*)((const f16*)xin + off);
+            const float* sp = scale + (long)t * K + c0;
+            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = (f16)((float)a[j] * s0[j]); o[4 + j] = (f16)((float)a[4 + j] * s1[j]); }
+            return o;
         } else {
             return *(const half8*)((const f16*)xin + off);
         }
@@ -622,15 +638,22 @@ bool pw_gemm_supported(int K, int N, int NBtot) {
 }
 
 // y fp32 [T][P][N] = W x (+ bias) (+ resid): x fp16 or fp32 [T][P][K]; W fragment-major hi + lo planes, w_tile_stride halfs per image
-hipError_t launch_pw_gemm(hipStream_t st, const void* x, bool x_f32, int K, const void* W, long w_tile_stride, const float* bias,
-                          const float* resid, float* y, int N, int NBtot, int T, int P) {
+static hipError_t pw_gemm_mode(hipStream_t st, int xmode, const void* x, int K, const void* W, long w_tile_stride, const float* bias,
+                               const float* resid, float* y, int N, int NBtot, int T, int P, const float* scale) {
     if (!pw_gemm_supported(K, N, NBtot) || T <= 0 || P <= 0) return hipErrorInvalidValue;
     const int passes = (NBtot + 3) / 4, nbw = (NBtot + passes - 1) / passes;       // <= 4 row blocks per workgroup, split evenly
     const dim3 grid((unsigned)((long)T * ((P + 127) / 128)), (unsigned)((NBtot + nbw - 1) / nbw)), block(256);
     const f16* Wh = (const f16*)W;
-#define IRA_GEMM(NBW_) \
-    do { if (x_f32) hipLaunchKernelGGL((k_pw_gemm<NBW_, true>), grid, block, 0, st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, P); \
-         else hipLaunchKernelGGL((k_pw_gemm<NBW_, false>), grid, block, 0, st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, P); } while (0)
+#define IRA_GEMM_M(NBW_, M_) hipLaunchKernelGGL((k_pw_gemm<NBW_, M_>), grid, block, 0, st, x, K, Wh, w_tile_stride, bias, resid, y, N, NBtot, T, P, scale)
+#define IRA_GEMM(NBW_)                                           \
+    do {                                                         \
+        switch (xmode) {                                         \
+            case IN_F32: IRA_GEMM_M(NBW_, IN_F32); break;        \
+            case IN_GATED: IRA_GEMM_M(NBW_, IN_GATED); break;    \
+            case IN_SCALED: IRA_GEMM_M(NBW_, IN_SCALED); break;  \
+            default: IRA_GEMM_M(NBW_, IN_F16); break;            \
+        }                                                        \
+    } while (0)
     switch (nbw) {
         case 1: IRA_GEMM(1); break;
         case 2: IRA_GEMM(2); break;
@@ -638,15 +661,22 @@ hipError_t launch_pw_gemm(hipStream_t st, const void* x, bool x_f32, int K, cons
         default: IRA_GEMM(4); break;
     }
 #undef IRA_GEMM
+#undef IRA_GEMM_M
     return hipGetLastError();
+}
+
+hipError_t launch_pw_gemm(hipStream_t st, const void* x, bool x_f32, int K, const void* W, long w_tile_stride, const float* bias,
+                          const float* resid, float* y, int N, int NBtot, int T, int P) {
+    return pw_gemm_mode(st, x_f32 ? IN_F32 : IN_F16, x, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, P, nullptr);
 }
 
 hipError_t launch_naf_pw(hipStream_t st, int inmode, int outmode, const void* x, int K, const void* W, long w_tile_stride,
                          const float* bias, const float* resid, float* y, int N, int NBtot, int T, int Hg, int Wg,
                          const float* scale) {
     if (inmode == IN_SCALED && scale == nullptr) return hipErrorInvalidValue;
-    if (outmode == OUT_RES && (inmode == IN_F16 || inmode == IN_F32) && pw_gemm_supported(K, N, NBtot) && T > 0 && Hg > 0 && Wg > 0)
-        return launch_pw_gemm(st, x, inmode == IN_F32, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg * Wg);
+    if (outmode == OUT_RES && (inmode == IN_F16 || inmode == IN_F32 || inmode == IN_GATED || inmode == IN_SCALED) && pw_gemm_supported(K, N, NBtot) &&
+        T > 0 && Hg > 0 && Wg > 0)
+        return pw_gemm_mode(st, inmode, x, K, W, w_tile_stride, bias, resid, y, N, NBtot, T, Hg * Wg, scale);
     if (K <= 0 || K % 16 != 0 || N % 8 != 0 || NBtot * 32 < N || T <= 0 || Hg <= 0 || Wg <= 0) return hipErrorInvalidValue;
     if ((inmode == IN_S2D || inmode == IN_S2DX2) && (K % 64 != 0)) return hipErrorInvalidValue;           // 4 taps x multiples of 16 channels
     if (outmode == OUT_SHUFFLE_ADD && (N % 32 != 0)) return hipErrorInvalidValue;  // N/4 channels, runs of 8
