@@ -111,6 +111,8 @@ def test_pw_kres(ctx, K, N, ln, in_f32, T, P, with_bias):
     (64, 0, False, 16, 3, 9, True, False, False),     # reduced
     (1024, 0, False, 384, 1, 33, True, False, False),  # latent project_out
     (48, 48, True, 48, 2, 31, False, False, False),
+    (128, 0, True, 160, 2, 300, True, False, True),    # k_pw_gemm: 5 row blocks as 3 + 2 (clamped partial chunk), several workgroups per image, fp32 pixels
+    (96, 0, False, 224, 1, 257, False, False, True),   # k_pw_gemm: 7 row blocks as 4 + 3, ragged last workgroup
 ])
 def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
     g = torch.Generator().manual_seed(K0 + 3 * N + K1)
