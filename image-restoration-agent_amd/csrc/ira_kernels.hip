@@ -566,42 +566,99 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
     }
 }
 
+// Two output rows per thread: the four input rows y - 1 .. y + 2 are each loaded once and feed both outputs (3 row loads per output
+// row become 2).  Per output the taps are still accumulated dy-major, dx-minor: bitwise the same as dw_block.
+template <int PX>
+__device__ __forceinline__ void dw_block2(const f16* __restrict__ in, const float* __restrict__ w,
+                                          const float* __restrict__ bias, int H, int W, int Cs, int t,
+                                          int y, int x0, int ch0, float (&acc)[2][PX][8]) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][p][e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int yy = y + r - 1;
+        if (yy < 0 || yy >= H) continue;
+        const f16* rowp = in + ((long)(t * H + yy) * W) * Cs + ch0;
+        half8 v[PX + 2];
+#pragma unroll
+        for (int i = 0; i < PX + 2; ++i) {
+            const int xx = x0 - 1 + i;
+            v[i] = (xx >= 0 && xx < W) ? *(const half8*)(rowp + (long)xx * Cs) : zero8();
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int dy = r - o;
+            if (dy < 0 || dy > 2) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
+                const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
+                float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+#pragma unroll
+                for (int p = 0; p < PX; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][p][e] = fmaf((float)v[p + dx][e], wv[e], acc[o][p][e]);
+            }
+        }
+    }
+    if (bias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float bv = bias[ch0 + e];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int p = 0; p < PX; ++p) acc[o][p][e] += bv;
+        }
+    }
+}
+
 constexpr int DW_PX = 4;   // pixels per thread: 4 x 8 register block (8 x 8 ran at 1 wave/SIMD)
 
 __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, f16* __restrict__ qk,
                                                     f16* __restrict__ v, int T, int H, int W, int C) {
-    const int WB = (W + 7) >> 3, XB = 2 * WB, G = (3 * C) >> 3, GQK = (2 * C) >> 3;
-    const long total = (long)T * H * XB * G;
+    const int WB = (W + 7) >> 3, XB = 2 * WB, G = (3 * C) >> 3, GQK = (2 * C) >> 3, HP = (H + 1) >> 1;
+    const long total = (long)T * HP * XB * G;
     const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long rest = idx / G;
     const int xq = (int)(rest % XB); rest /= XB;     // 4-pixel block index along the (padded) row
-    const int y = (int)(rest % H);
-    const int t = (int)(rest / H);
+    const int y0 = 2 * (int)(rest % HP);             // two output rows per thread
+    const int t = (int)(rest / HP);
     const int x0 = xq * DW_PX;
-    float acc[DW_PX][8];
-    dw_block<DW_PX>(in, w, bias, H, W, 3 * C, t, y, x0, g * 8, acc);
-    if (g < GQK) {
-        // pixel-minor [T][H][WB][2C][8]: this thread owns half (4 pixels) of each 8-pixel vector
-        f16* dst = qk + ((((long)(t * H + y) * WB + (xq >> 1)) * (2 * C)) + g * 8) * 8 + 4 * (xq & 1);
+    float acc2[2][DW_PX][8];
+    dw_block2<DW_PX>(in, w, bias, H, W, 3 * C, t, y0, x0, g * 8, acc2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            half4 o;
+    for (int o = 0; o < 2; ++o) {
+        const int y = y0 + o;
+        if (y >= H) break;
+        float (&acc)[DW_PX][8] = acc2[o];
+        if (g < GQK) {
+            // pixel-minor [T][H][WB][2C][8]: this thread owns half (4 pixels) of each 8-pixel vector
+            f16* dst = qk + ((((long)(t * H + y) * WB + (xq >> 1)) * (2 * C)) + g * 8) * 8 + 4 * (xq & 1);
 #pragma unroll
-            for (int p = 0; p < DW_PX; ++p) o[p] = (x0 + p < W) ? (f16)acc[p][e] : (f16)0.f;
-            *(half4*)(dst + e * 8) = o;
-        }
-    } else {
-        f16* dst = v + ((long)(t * H + y) * W + x0) * C + (g - GQK) * 8;
+            for (int e = 0; e < 8; ++e) {
+                half4 o4;
 #pragma unroll
-        for (int p = 0; p < DW_PX; ++p) {
-            if (x0 + p < W) {
-                half8 o;
+                for (int p = 0; p < DW_PX; ++p) o4[p] = (x0 + p < W) ? (f16)acc[p][e] : (f16)0.f;
+                *(half4*)(dst + e * 8) = o4;
+            }
+        } else {
+            f16* dst = v + ((long)(t * H + y) * W + x0) * C + (g - GQK) * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)acc[p][e];
-                *(half8*)(dst + (long)p * C) = o;
+            for (int p = 0; p < DW_PX; ++p) {
+                if (x0 + p < W) {
+                    half8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (f16)acc[p][e];
+                    *(half8*)(dst + (long)p * C) = o8;
+                }
             }
         }
     }
@@ -1524,7 +1581,7 @@ hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1
 hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias, void* qk, void* v,
                              int T, int H, int W, int C) {
     if (C % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)T * H * (2 * ((W + 7) / 8)) * (3 * C / 8);
+    const long total = (long)T * ((H + 1) / 2) * (2 * ((W + 7) / 8)) * (3 * C / 8);      // two output rows per thread
     hipLaunchKernelGGL(k_dwconv_qkv, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)qk,
                        (f16*)v, T, H, W, C);
     return hipGetLastError();
