@@ -30,6 +30,46 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense
 
 
+def csrc_sha():
+    """sha1 over the kernel sources: profiles/traffic.json (PMC bytes per launch, written by tools/prof_summary.py from rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of THIS script) is only quoted when it was measured on the sources that are running."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'image-restoration-agent_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'image-restoration-agent_amd', 'csrc', '*.h'))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, 'rb').read())
+    return hsh.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """(bytes per launch, note) from profiles/traffic.json if its stamp matches the running sources, else (None, why)."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tpath):
+        return None, 'no PMC pass committed'
+    try:
+        tj = json.load(open(tpath))
+    except Exception as e:
+        return None, f'unreadable traffic.json: {e}'
+    stamp = tj.get('_stamp', {})
+    if stamp.get('csrc_sha') != csrc_sha():
+        return None, f"stale: PMC pass was taken on csrc {stamp.get('csrc_sha')}, running {csrc_sha()} (re-run tools/prof_gpu.sh + tools/prof_summary.py)"
+    return tj.get(key), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this script on csrc {stamp.get('csrc_sha')} ({stamp.get('when', '?')}): 2 x FETCH_SIZE + WRITE_SIZE per launch"
+
+
+def finish_roofline(roof, key, alg_bytes, avg_ms):
+    """roofline.achieved is the SURVEY 8d ALGORITHMIC bytes of the kernel's fusion group / its launch time (the contract figure, credit
+    for fusing past the contract included); the bytes the kernel really moved and the real HBM rate are reported next to it."""
+    roof['basis'] = 'algorithmic bytes of the SURVEY 8d fusion contract per launch / HIP-event launch time (NOT measured HBM traffic: see measured_hbm)'
+    tr, note = measured_traffic(key)
+    roof['traffic'] = tr
+    roof['traffic_source'] = note
+    if tr:
+        gbs = tr / 1e9 / (avg_ms / 1e3)
+        roof['measured_hbm'] = {'GBps': round(gbs, 1), 'frac_of_peak': round(gbs / HBM_PEAK_GBS, 4), 'bytes_over_algorithmic': round(tr / max(alg_bytes, 1), 3)}
+    return roof
+
+
 def algorithmic_elements_per_px(cfg):
     """SURVEY 8d fusion contract: 14C + 6Hf elements per level-pixel per TransformerBlock, summed with
     the level down-sampling, + 513 glue elements (embed, down/up, reduce, output+skip) for the default
@@ -55,6 +95,7 @@ def family_elements(family, C, Hf):
         'pout_res': Hf + 2 * C,       # G6
         'qkv_fused': 8 * C,           # G1 + G2 in one kernel
         'ffn_fused': 3 * C + 6 * Hf,  # G4 + G5 + G6 in one kernel (its real HBM traffic is ~2.3C: see DESIGN.md)
+        'attn_ffn_fused': 6 * C + 6 * Hf,   # G3 + G4 + G5 + G6: the attention apply folded into the fused GDFN (csrc/ira_ffn2.hip)
     }.get(family, 0)
 
 
@@ -186,12 +227,7 @@ def main_nafnet(args):
                          'launches_per_step': prof[key]['launches'], 'algorithmic_bytes_per_launch': int(alg),
                          'share_of_step': round(prof[key]['ms'] / tot, 4)})
             roof['frac'] = round(roof['achieved'] / HBM_PEAK_GBS, 4)
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tpath):
-                try:
-                    roof['traffic'] = json.load(open(tpath)).get(key)
-                except Exception:
-                    roof['traffic'] = None
+            finish_roofline(roof, key, alg, avg_ms)
         result['roofline'] = roof
         result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
         result['kernel_ms_total_profiled'] = round(tot, 3)
@@ -698,7 +734,8 @@ def main():
                                    f'tile {th} overlap {args.overlap} -> {n_tiles} tiles ({computed_px / 1e6:.2f} MP computed), '
                                    + (f'{world} horizontal band(s) with halo-row and Gram exchange' if whole else f'tile-parallel over {world} GPU(s)'),
                        'frames_per_s': round(value / mp_out, 4), 'tiles': n_tiles,
-                       'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
+                       'device_ms_per_step_rank0': round(dev_ms / args.steps, 3),
+                       'timed_region': 'frame resident in HBM before the timed region, uint8 result left in HBM; the H2D / D2H copies of the host-buffer entry (24.9 MB each way) are outside it'},
             'net_roofline': {'bound': 'hbm', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
                              'achieved': round(net_bytes / 1e9 / (elapsed / args.steps) / world, 1), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s per GPU', 'frac': round(net_bytes / 1e9 / (elapsed / args.steps) / world / HBM_PEAK_GBS, 4)},
@@ -730,12 +767,7 @@ def main():
                          'launches_per_step': prof[key]['launches'], 'algorithmic_bytes_per_launch': int(alg),
                          'share_of_step': round(prof[key]['ms'] / tot, 4)})
             roof['frac'] = round(roof['achieved'] / HBM_PEAK_GBS, 4)
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # PMC bytes per launch, measured offline
-            if os.path.exists(tpath):
-                try:
-                    roof['traffic'] = json.load(open(tpath)).get(key)
-                except Exception:
-                    roof['traffic'] = None
+            finish_roofline(roof, key, alg, avg_ms)
         result['roofline'] = roof
         result['kernel_time_share'] = {k: round(v / tot, 4) for k, v in sorted(fam_tot.items(), key=lambda kv: -kv[1])}
         result['kernel_ms_total_profiled'] = round(tot, 3)
@@ -743,11 +775,53 @@ def main():
         result['roofline'] = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
                               'traffic': None, 'note': 'per-kernel timing is collected at N=1 only'}
 
-    # ---- CPU baseline: the oracle (torch CPU fp32 restatement of the reference) on a bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baseline + PSNR delta: the oracle (torch CPU fp32 restatement of the reference) on a bounded sample of the SAME
+    # workload: 1 warm-up + 3 timed 512x512 tiles of this frame, each compared with the tile the GPU just produced
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not whole:
         from oracle import restormer_oracle as O
         from ira_amd.weights import to_torch
         cores = min(16, os.cpu_count() or 1)          # one-GPU box share
+        torch.set_num_threads(cores)
+        sd = to_torch(seeded_state_dict(cfg, 0))
+        stride_h, stride_w = th - args.overlap, tw - args.overlap
+        hi = O.tile_index_list(Hp, th, stride_h); wi = O.tile_index_list(Wp, tw, stride_w)
+        picks = sorted({0, (n_tiles // 2 + n_cols // 2 - 1) % n_tiles, n_tiles - 1})       # first, an interior one, last (flush with both far edges)
+        gt = torch.empty((1, th, tw, 3), dtype=torch.float32, device=dev)
+        u8 = lambda t: O.img_as_ubyte(np.clip(t, 0, 1).astype(np.float32))   # noqa: E731
+
+        def crop(k):
+            y0, x0 = hi[k // n_cols], wi[k % n_cols]
+            return y0, x0, torch.from_numpy(noisy[y0:y0 + th, x0:x0 + tw]).float().div(255.).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            O.restormer_forward(crop(picks[0])[2], sd, cfg.to_dict())                        # warm-up
+            dts, deltas, psnrs = [], [], []
+            for k in picks:
+                y0, x0, x = crop(k)
+                t1 = time.perf_counter()
+                yo = O.restormer_forward(x, sd, cfg.to_dict())
+                dts.append(time.perf_counter() - t1)
+                be.restore_tiles_device(frame.data_ptr(), h, w, 3, args.tile, args.overlap, k, 1, gt.data_ptr())
+                be.sync()
+                yb, yo = gt[0].cpu().numpy(), yo[0].permute(1, 2, 0).numpy()
+                cl = clean[y0:y0 + th, x0:x0 + tw]
+                deltas.append(O.psnr_u8(u8(yb), cl) - O.psnr_u8(u8(yo), cl))
+                psnrs.append(O.psnr_f(yb, yo))
+        dt = sum(dts) / len(dts)
+        tile_mps = th * tw / 1e6 / dt
+        worst = max(deltas, key=abs)
+        result['psnr_delta_db'] = float(f'{worst:.3e}')          # PSNR(build_u8, clean) - PSNR(oracle_u8, clean), worst of the checked tiles
+        result['psnr_check'] = {'definition': 'PSNR(build_u8, clean_u8) - PSNR(oracle_u8, clean_u8), RST/Denoising/utils.py:10-25, bar 1e-3 dB',
+                                'tiles_checked': picks, 'delta_db': [float(f'{d:.3e}') for d in deltas],
+                                'psnr_build_vs_oracle_db': [round(p, 2) for p in psnrs], 'within_bar': bool(abs(worst) <= 1e-3)}
+        result['cpu_baseline'] = {
+            'value': round(tile_mps * (h * w) / computed_px, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/restormer_oracle.py (torch {torch.__version__} CPU fp32), {len(picks)} timed forwards of {th}x{tw} tiles {picks} of this frame '
+                      f'after 1 warm-up ({dt:.2f} s each = {tile_mps:.5f} computed MP/s); value = that rate x output/computed '
+                      f'pixel ratio {h * w / computed_px:.4f} of the 4K tiling'}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import restormer_oracle as O
+        from ira_amd.weights import to_torch
+        cores = min(16, os.cpu_count() or 1)
         torch.set_num_threads(cores)
         sd = to_torch(seeded_state_dict(cfg, 0))
         S = 256
@@ -757,14 +831,10 @@ def main():
             t1 = time.perf_counter()
             reps = 2
             for _ in range(reps):
-                y = O.restormer_forward(x, sd, cfg.to_dict())
+                O.restormer_forward(x, sd, cfg.to_dict())
             dt = (time.perf_counter() - t1) / reps
-        tile_mps = S * S / 1e6 / dt
-        result['cpu_baseline'] = {
-            'value': round(tile_mps * (h * w) / computed_px, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/restormer_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {S}x{S} tile '
-                      f'after 1 warm-up ({dt:.2f} s each = {tile_mps:.5f} computed MP/s); value = that rate x output/computed '
-                      f'pixel ratio {h * w / computed_px:.4f} of the 4K tiling'}
+        result['cpu_baseline'] = {'value': round(S * S / 1e6 / dt, 5), 'unit': 'MP/s', 'cores': cores, 'kind': 'port',
+                                  'sample': f'oracle/restormer_oracle.py (torch {torch.__version__} CPU fp32), {reps} timed forwards of one {S}x{S} crop after 1 warm-up ({dt:.2f} s each)'}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -350,12 +350,8 @@ template <int C, int LN, bool BIN, bool CB>
 static hipError_t ffn_launch2(hipStream_t st, const float* x, float* xo, const f16* Win, const float* bin, const float* dww,
                               const float* dwb, const f16* Wout, const float* bout, int T, int H, int W, int Hp) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_fused<C, LN, BIN, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FFN_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn_fused<C, LN, BIN, CB>, FFN_LDS, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_ffn_fused<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(512), FFN_LDS, st, x, xo, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
     return hipGetLastError();
 }
@@ -381,9 +377,6 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* xo, int ln_mo
                             const float* dww, const float* dwb, const void* Wout, const float* bout, int T, int H, int W,
                             int Hp) {
     if (x == xo || (ln_mode != 1 && ln_mode != 2) || !ffn_fused_supported(C, Hp)) return hipErrorInvalidValue;
-    // 12-wave experiment (ira_ffn_fused12.hip): ties at C = 48, spills and loses 7 % at C = 96 -> opt-in only
-    static const int use12 = getenv("IRA_FFN12") ? atoi(getenv("IRA_FFN12")) : 0;
-    if (use12) return launch_ffn_fused12(st, x, xo, ln_mode, C, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp);
     if (C == 48) return ffn_launch<48>(st, x, xo, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
     return ffn_launch<96>(st, x, xo, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
 }

@@ -4,7 +4,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ira {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (function, device): raise it once per device (a process may hold handles on
+// several GPUs, driven from several host threads).  `mask` is one static word per kernel instantiation, bit d = done on device d.
+inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // All launchers enqueue on `st` and return hipGetLastError(). T = tiles, P = pixels per tile.
 
@@ -39,10 +54,12 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln
                             const float* bin, const float* dww, const float* dwb, const void* Wout, const float* bout,
                             int T, int H, int W, int Hp);
 
-// 12-wave variant (ira_ffn_fused12.hip): one producer + two consumer waves per SIMD.
-hipError_t launch_ffn_fused12(hipStream_t st, const float* x, float* x_out, int ln_mode, int C, const void* Win,
-                              const float* bin, const float* dww, const float* dwb, const void* Wout, const float* bout,
-                              int T, int H, int W, int Hp);
+// Fused attention apply + GDFN, second generation (ira_ffn2.hip): x_out = x1 + ffn(LN(x1)), x1 = x + M_t . v (+ wo_b); v == M == nullptr: x1 = x.
+// M: the per-tile matrices of launch_attn_mix (fp16 hi + lo planes, fragment-major), m_tile_stride in halfs.
+bool ffn2_supported(int C, int Hp);
+hipError_t launch_ffn2(hipStream_t st, const float* x, float* x_out, const void* v, const void* M, long m_tile_stride, const float* wo_b,
+                       int ln_mode, int C, const void* Win, const float* bin, const float* dww, const float* dwb, const void* Wout,
+                       const float* bout, int T, int H, int W, int Hp);
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope = 0.f,

@@ -1454,8 +1454,8 @@ static hipError_t pw_kres_lds_launch_nw(hipStream_t st, const void* x, bool in_f
     const size_t smem = (size_t)2 * 2 * KS * 1024;
 #define IRA_KL(LN_, F32_)                                                                                               \
     do {                                                                                                                \
-        static bool done_ = false;                                                                                      \
-        if (!done_) { hipError_t e_ = hipFuncSetAttribute((const void*)k_pw_kres_lds<KS, LN_, F32_, NW, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e_ != hipSuccess) return e_; done_ = true; } \
+        static std::atomic<uint64_t> done_{0};                                                                          \
+        if (hipError_t e_ = ensure_dynamic_lds((const void*)k_pw_kres_lds<KS, LN_, F32_, NW, MINW>, smem, done_); e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((k_pw_kres_lds<KS, LN_, F32_, NW, MINW>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);      \
     } while (0)
     if (in_f32) {

@@ -22,6 +22,7 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
     const float* temp = nullptr;  const float* wo = nullptr; const float* wo_b = nullptr;
     const void* pin_w = nullptr;  const float* pin_b = nullptr;
     const float* dw2_w = nullptr; const float* dw2_b = nullptr;
+    const float* dw2_u = nullptr; const float* dw2_ub = nullptr;   // the same weights per vector-work unit (ira_ffn2.hip; pack.py::_dw_unit_pack)
     const void* pout_w = nullptr; const float* pout_b = nullptr;
     // X-Restormer only (xrestormer_arch.py:239-262): OCAB and the second GDFN; level = index into spatial_heads
     int level = 0;
@@ -29,6 +30,7 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
     const void* oc_proj_w = nullptr; const float* oc_proj_b = nullptr;
     const void* pin2_w = nullptr; const float* pin2_b = nullptr;
     const float* dw3_w = nullptr; const float* dw3_b = nullptr;
+    const float* dw3_u = nullptr; const float* dw3_ub = nullptr;
     const void* pout2_w = nullptr; const float* pout2_b = nullptr;
 };
 
@@ -116,6 +118,7 @@ struct ira_model {
     float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
     float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
     bool use_fused_ffn = true;
+    int ffn_gen = 2;                  // 2: ira_ffn2.hip (attention apply folded in); 1: ira_ffn_fused.hip + separate apply (IRA_FFN_GEN=1)
     // strip-parallel whole-frame forward (ira_strip_*): this rank's band of rows with halo rows of its neighbours
     bool strip_set = false, strip_on = false;
     ira_strip_comm scomm{};

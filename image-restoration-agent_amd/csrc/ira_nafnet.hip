@@ -721,12 +721,8 @@ static hipError_t naf_tail_launch(hipStream_t st, const void* g, const float* sc
                                   const void* W4, const float* b4, const void* W5, const float* b5, int T, int P) {
     constexpr int NB = C / 32, KS = C / 16;
     const size_t smem = (size_t)(2 * (2 * NB * KS) + 4 * NB * KS) * 1024 + (size_t)4 * C * sizeof(float);
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_naf_tail<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_naf_tail<C>, smem, done); e != hipSuccess) return e;
     const int chunks = (P + 31) / 32;
     const int wg_per_tile = (chunks + 4 * TAIL_ITER - 1) / (4 * TAIL_ITER);
     hipLaunchKernelGGL((k_naf_tail<C>), dim3((unsigned)((long)T * wg_per_tile)), dim3(256), smem, st, (const f16*)g, scale, x,

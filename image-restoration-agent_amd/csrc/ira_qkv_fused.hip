@@ -262,12 +262,8 @@ template <int C, int LN, bool BIN, bool CB>
 static hipError_t qkv_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww,
                               const float* dwb, f16* qk, f16* v, int T, int H, int W) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_fused<C, LN, BIN, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QKV_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv_fused<C, LN, BIN, CB>, QKV_LDS, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_qkv_fused<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(512), QKV_LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
     return hipGetLastError();
 }

@@ -43,6 +43,8 @@ static bool load_block(ira_model* m, const std::string& p, int C, int heads, int
     b.pin_b = (const float*)wptr(m, p + ".pin_b", cb || lb, (size_t)2 * Hp * 4);
     b.dw2_w = (const float*)wptr(m, p + ".dw2_w", true, (size_t)9 * 2 * Hp * 4);
     b.dw2_b = (const float*)wptr(m, p + ".dw2_b", cb, (size_t)2 * Hp * 4);
+    b.dw2_u = (const float*)wptr(m, p + ".dw2_u", false, (size_t)9 * 2 * Hp * 4);
+    b.dw2_ub = (const float*)wptr(m, p + ".dw2_ub", false, (size_t)2 * Hp * 4);
     b.pout_w = wptr(m, p + ".pout_w", true, 2 * NBc * Hp * 2);
     b.pout_b = (const float*)wptr(m, p + ".pout_b", cb, NBc * 4);
     b.level = level;
@@ -57,6 +59,8 @@ static bool load_block(ira_model* m, const std::string& p, int C, int heads, int
         b.pin2_b = (const float*)wptr(m, p + ".pin2_b", cb || lb, (size_t)2 * Hp * 4);
         b.dw3_w = (const float*)wptr(m, p + ".dw3_w", true, (size_t)9 * 2 * Hp * 4);
         b.dw3_b = (const float*)wptr(m, p + ".dw3_b", cb, (size_t)2 * Hp * 4);
+        b.dw3_u = (const float*)wptr(m, p + ".dw3_u", false, (size_t)9 * 2 * Hp * 4);
+        b.dw3_ub = (const float*)wptr(m, p + ".dw3_ub", false, (size_t)2 * Hp * 4);
         b.pout2_w = wptr(m, p + ".pout2_w", true, 2 * NBc * Hp * 2);
         b.pout2_b = (const float*)wptr(m, p + ".pout2_b", cb, NBc * 4);
     }
@@ -158,9 +162,16 @@ static int ensure_workspace(ira_model* m, int T, int H, int W) {
     return IRA_OK;
 }
 
-// GDFN + residual (restormer_arch.py:88-93,149): fused kernel where supported (writes x -> alt, the two are swapped), else three kernels
-static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const float* dw_w, const float* dw_b, const void* pout_w,
-                   const float* pout_b, float*& x, float*& alt, int T, int H, int W, int C, int Hp) {
+// GDFN + residual (restormer_arch.py:88-93,149): fused kernel where supported (writes x -> alt, the two are swapped), else three kernels.
+// v != nullptr: the attention apply x += M_t . v (+ wo_b) of the same block has NOT been run and is folded into the fused kernel
+// (ira_ffn2.hip); callers pass it only when ffn2_usable() said yes.
+static bool ffn2_usable(const ira_model* m, const float* dw_u, const float* dw_ub, const float* dw_b, const float* alt, int C, int Hp) {
+    return alt != nullptr && m->use_fused_ffn && m->ffn_gen == 2 && dw_u != nullptr && (dw_b == nullptr || dw_ub != nullptr) && ira::ffn2_supported(C, Hp);
+}
+
+static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const float* dw_w, const float* dw_b, const float* dw_u,
+                   const float* dw_ub, const void* pout_w, const float* pout_b, float*& x, float*& alt, int T, int H, int W, int C, int Hp,
+                   const void* v = nullptr, const void* M = nullptr, long m_stride = 0, const float* wo_b = nullptr) {
     const int P = H * W, NBc = up32(C) / 32;
     const int ln = m->cfg.ln_with_bias ? 2 : 1;
     hipStream_t st = m->st;
@@ -171,6 +182,14 @@ static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const fl
     } else {
         for (int i = 0; i < 3; ++i) k_[i][0] = 0;
     }
+    if (ffn2_usable(m, dw_u, dw_ub, dw_b, alt, C, Hp)) {
+        char kf[64];
+        if (m->profile) snprintf(kf, sizeof kf, "%s|C%d|%dx%d|T%d", v ? "attn_ffn_fused" : "ffn_fused", C, H, W, T); else kf[0] = 0;
+        RUN(m, kf, ira::launch_ffn2(st, x, alt, v, M, m_stride, wo_b, ln, C, pin_w, pin_b, dw_u, dw_b ? dw_ub : nullptr, pout_w, pout_b, T, H, W, Hp));
+        std::swap(x, alt);
+        return IRA_OK;
+    }
+    if (v != nullptr) return m->fail(IRA_ERR_ARG, "run_ffn: attention fold requested without the second-generation fused kernel");
     if (alt != nullptr && m->use_fused_ffn && ira::ffn_fused_supported(C, Hp)) {
         char kf[64];
         if (m->profile) snprintf(kf, sizeof kf, "ffn_fused|C%d|%dx%d|T%d", C, H, W, T); else kf[0] = 0;
@@ -258,10 +277,16 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
         RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
         RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
     }
-    RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, 2L * NBc * 32 * C, b.wo_b, x, x, C, NBc, T, P));
-    // GDFN (:88-93)
-    if ((rc = strip_halo(m, x, H, W, C, lv)) != IRA_OK) return rc;
-    rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp);
+    // attention apply x += M_t . v (:127-131 as a per-tile 1x1) and GDFN (:88-93): ONE kernel where the second-generation fused
+    // kernel runs (not in band mode: the halo row of x has to be exchanged between the two there)
+    const long m_stride = 2L * NBc * 32 * C;
+    const bool fold = !m->strip_on && ffn2_usable(m, b.dw2_u, b.dw2_ub, b.dw2_b, alt, C, Hp);
+    if (!fold) {
+        RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, m_stride, b.wo_b, x, x, C, NBc, T, P));
+        if ((rc = strip_halo(m, x, H, W, C, lv)) != IRA_OK) return rc;
+    }
+    rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.dw2_u, b.dw2_ub, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp,
+                 fold ? m->v : nullptr, fold ? m->M : nullptr, m_stride, b.wo_b);
     if (rc != IRA_OK || !m->xr) return rc;
     // X-Restormer (xrestormer_arch.py:260-261): x += OCAB(norm3(x)); x += spatial_ffn(norm4(x))
     const int sheads = m->xr_spatial_heads[b.level], inner = 16 * sheads, NBo = up32(3 * inner) / 32;
@@ -275,7 +300,7 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     RUN(m, ko[0], ira::launch_pw_kres(st, x, true, ln, C, b.oc_qkv_w, b.oc_qkv_b, m->qkvp, 3 * inner, 3 * inner, NBo, T, P));
     RUN(m, ko[1], ira::launch_ocab_attn(st, m->qkvp, b.oc_rel, m->v, T, H, W, sheads));
     RUN(m, ko[2], ira::launch_pw_nres(st, m->v, inner, nullptr, 0, false, b.oc_proj_w, 0, b.oc_proj_b, x, x, C, NBc, T, P));
-    return run_ffn(m, b.pin2_w, b.pin2_b, b.dw3_w, b.dw3_b, b.pout2_w, b.pout2_b, x, alt, T, H, W, C, Hp);
+    return run_ffn(m, b.pin2_w, b.pin2_b, b.dw3_w, b.dw3_b, b.dw3_u, b.dw3_ub, b.pout2_w, b.pout2_b, x, alt, T, H, W, C, Hp);
 }
 
 static int run_stage(ira_model* m, const std::vector<Blk>& blks, float*& x, float* alt, int T, int H, int W, int C, int heads, int Hp, int lv) {

@@ -131,6 +131,7 @@ static int create_common(int device, const void* blob, size_t bytes, ira_model**
 
     ira_model* m = new ira_model();
     m->device = device;
+    if (const char* gen = getenv("IRA_FFN_GEN")) m->ffn_gen = atoi(gen) == 1 ? 1 : 2;      // A/B switch (ira_set_ffn_generation)
     const TocEntry* te = (const TocEntry*)((const char*)blob + sizeof(BlobHeader));
     for (uint32_t i = 0; i < hd->n_entries; ++i) {
         if (te[i].offset + te[i].nbytes > bytes || te[i].offset % 256 != 0) {
@@ -745,6 +746,19 @@ int ira_op_conv3x3(ira_model_t* m, const float* in, const void* W, const float* 
 int ira_op_ffn_fused(ira_model_t* m, const float* x, float* xo, int ln_mode, int C, const void* Win, const float* bin,
                      const float* dww, const float* dwb, const void* Wout, const float* bout, int T, int H, int W, int Hp) {
     OP_BODY(m, "op", ira::launch_ffn_fused(m->st, x, xo, ln_mode, C, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp));
+}
+
+int ira_op_ffn2(ira_model_t* m, const float* x, float* xo, const void* v, const void* M, long m_tile_stride, const float* wo_b, int ln_mode,
+                int C, const void* Win, const float* bin, const float* dwu, const float* dwub, const void* Wout, const float* bout, int T,
+                int H, int W, int Hp) {
+    OP_BODY(m, "op", ira::launch_ffn2(m->st, x, xo, v, M, m_tile_stride, wo_b, ln_mode, C, Win, bin, dwu, dwub, Wout, bout, T, H, W, Hp));
+}
+
+int ira_set_ffn_generation(ira_model_t* m, int gen) {
+    ENTER(m);
+    if (gen != 1 && gen != 2) return m->fail(IRA_ERR_ARG, "ffn generation must be 1 or 2");
+    m->ffn_gen = gen;
+    return IRA_OK;
 }
 
 int ira_op_qkv_fused(ira_model_t* m, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,

@@ -116,6 +116,8 @@ SIGNATURES = {
     'ira_op_attn_mix': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     'ira_op_conv3x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     'ira_op_ffn_fused': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_op_ffn2': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_set_ffn_generation': (_i, [_vp, _i]),
     'ira_op_qkv_fused': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'ira_set_fused_ffn': (_i, [_vp, _i]),
     'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),

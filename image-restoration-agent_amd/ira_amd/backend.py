@@ -162,6 +162,9 @@ class _Backend:
     def set_fused_ffn(self, on: bool):
         self._ck(self._lib.ira_set_fused_ffn(self._h, 1 if on else 0), 'ira_set_fused_ffn')
 
+    def set_ffn_generation(self, gen: int):
+        self._ck(self._lib.ira_set_ffn_generation(self._h, int(gen)), 'ira_set_ffn_generation')
+
     def sync(self):
         self._ck(self._lib.ira_sync(self._h), 'ira_sync')
 

@@ -85,6 +85,19 @@ def _dw_pack(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.reshape(ch, 9).T.astype(np.float32))     # [9][ch]
 
 
+def _dw_unit_pack(w9: np.ndarray, hp: int) -> np.ndarray:
+    """[9][2hp] tap-major depthwise weights -> [hp/16][2][9][16] for csrc/ira_ffn2.hip: everything ONE vector-work unit (16-channel
+    chunk c of the GDFN hidden width, channel octet oc) needs is 144 contiguous floats, per tap [x1 channels 16c+8oc.. (8) |
+    gate channels hp+16c+8oc.. (8)], so the kernel fetches a tap with one s_load_dwordx16 at an immediate offset."""
+    a = w9.reshape(9, 2, hp // 16, 2, 8)                          # [tap][x1|x2][c][oc][e]
+    return np.ascontiguousarray(a.transpose(2, 3, 0, 1, 4).reshape(hp // 16, 2, 9, 16).astype(np.float32))
+
+
+def _dw_unit_bias(b: np.ndarray, hp: int) -> np.ndarray:
+    a = b.reshape(2, hp // 16, 2, 8)                              # [x1|x2][c][oc][e]
+    return np.ascontiguousarray(a.transpose(1, 2, 0, 3).reshape(hp // 16, 2, 16).astype(np.float32))
+
+
 def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, name: str):
     with_bias_ln = cfg.LayerNorm_type != 'BiasFree'
     hp = up32(hid)
@@ -112,6 +125,7 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
 
     out[f'{name}.dw1_w'] = _dw_pack(_np(sd[f'{p}.attn.qkv_dwconv.weight']))
     out[f'{name}.dw2_w'] = _dw_pack(_hidden_remap(_np(sd[f'{p}.ffn.dwconv.weight']), hid, hp))
+    out[f'{name}.dw2_u'] = _dw_unit_pack(out[f'{name}.dw2_w'], hp)
     out[f'{name}.temp'] = _np(sd[f'{p}.attn.temperature']).reshape(-1).astype(np.float32)
     out[f'{name}.wo'] = np.ascontiguousarray(_np(sd[f'{p}.attn.project_out.weight'])[:, :, 0, 0])
     wout = np.zeros((up32(dim), hp), np.float64)
@@ -120,6 +134,7 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     if cfg.bias:
         out[f'{name}.dw1_b'] = _np(sd[f'{p}.attn.qkv_dwconv.bias']).astype(np.float32)
         out[f'{name}.dw2_b'] = _hidden_remap(_np(sd[f'{p}.ffn.dwconv.bias']).astype(np.float32), hid, hp)
+        out[f'{name}.dw2_ub'] = _dw_unit_bias(out[f'{name}.dw2_b'], hp)
         out[f'{name}.wo_b'] = _pad_rows(_np(sd[f'{p}.attn.project_out.bias']).astype(np.float32), up32(dim))
         out[f'{name}.pout_b'] = _pad_rows(_np(sd[f'{p}.ffn.project_out.bias']).astype(np.float32), up32(dim))
 

@@ -165,7 +165,7 @@ def xrestormer_cfg_struct(cfg: XRestormerConfig):
 
 
 def pack_xrestormer_arrays(sd, cfg: XRestormerConfig) -> dict:
-    from .pack import pack_arrays, frag_major, split16, up32, _np, _pad_rows, _hidden_remap, _dw_pack
+    from .pack import pack_arrays, frag_major, split16, up32, _np, _pad_rows, _hidden_remap, _dw_pack, _dw_unit_pack, _dw_unit_bias
     rcfg = restormer_equivalent(cfg)
     tr = {}
     for k, v in sd.items():
@@ -213,12 +213,14 @@ def pack_xrestormer_arrays(sd, cfg: XRestormerConfig) -> dict:
             if has_b:
                 out[f'{o}.pin2_b'] = _hidden_remap(bi.astype(np.float32), hid, hp)
             out[f'{o}.dw3_w'] = _dw_pack(_hidden_remap(_np(sd[f'{p}.spatial_ffn.dwconv.weight']), hid, hp))
+            out[f'{o}.dw3_u'] = _dw_unit_pack(out[f'{o}.dw3_w'], hp)
             wout = np.zeros((up32(dim), hp), np.float64)
             wout[:dim, :hid] = f64(f'{p}.spatial_ffn.project_out.weight')[:, :, 0, 0]
             out[f'{o}.pout2_w'] = frag_major(split16(wout))
             if cfg.bias:
                 out[f'{o}.oc_proj_b'] = _pad_rows(_np(sd[f'{p}.spatial_attn.project_out.bias']).astype(np.float32), up32(dim))
                 out[f'{o}.dw3_b'] = _hidden_remap(_np(sd[f'{p}.spatial_ffn.dwconv.bias']).astype(np.float32), hid, hp)
+                out[f'{o}.dw3_ub'] = _dw_unit_bias(out[f'{o}.dw3_b'], hp)
                 out[f'{o}.pout2_b'] = _pad_rows(_np(sd[f'{p}.spatial_ffn.project_out.bias']).astype(np.float32), up32(dim))
     return out
 

@@ -333,6 +333,19 @@ int ira_op_ffn_fused(ira_model_t* m, const float* x_dev, float* x_out_dev, int l
                      const void* Win_dev, const float* bin_dev, const float* dww_dev, const float* dwb_dev,
                      const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
 
+/* Fused attention apply + GDFN block, second generation (csrc/ira_ffn2.hip), one kernel; C in {48, 96}:
+ *   x1 = x + M_t . v (+ wo_b)   (restormer_arch.py:127-131 re-associated as ira_op_attn_mix does),   x_out = x1 + ffn(LN(x1))  (:88-93,:149).
+ * v fp16 NHWC (T,H,W,C) and M (the fp16 hi/lo fragment-major matrices ira_op_attn_mix writes, m_tile_stride halfs per tile) may both
+ * be NULL: x1 = x, the plain GDFN block.  dwu fp32 [Hp/16][2][9][16] = the depthwise weights per (16-channel chunk, octet) unit
+ * (ira_amd/pack.py::_dw_unit_pack), dwub fp32 [Hp/16][2][16] or NULL; the other arguments as ira_op_ffn_fused.  x_out must not alias x. */
+int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void* v_dev, const void* M_dev, long m_tile_stride,
+                const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev, const float* dwu_dev,
+                const float* dwub_dev, const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
+
+/* Which fused GDFN kernel the Restormer schedule uses: 2 (default) = ira_op_ffn2 with the attention apply folded in, 1 = ira_op_ffn_fused
+ * after a separate apply kernel.  For A/B measurements; also settable with the environment variable IRA_FFN_GEN at create time. */
+int ira_set_ffn_generation(ira_model_t* m, int gen);
+
 /* Fused attention front end: LN + qkv 1x1 + depthwise 3x3 (restormer_arch.py:105-106,114) in one kernel; C in {48, 96}.
  * x fp32 NHWC (T,H,W,C); Wq packed qkv weights (LN gain folded, hi/lo, fragment-major), bq fp32 or NULL; dww fp32
  * [9][3C], dwb [3C] or NULL; outputs as ira_op_dwconv_qkv: q,k pixel-minor (T,H,ceil(W/8),2C,8), v NHWC (T,H,W,C). */

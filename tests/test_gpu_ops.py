@@ -369,6 +369,109 @@ def test_ffn_fused(ctx, C, hid, ln, T, H, W, bias):
     assert err <= 4e-3 * scale + 1e-4, (err, scale)
 
 
+def _ffn_block_sd(C, hid, ln, bias, g):
+    sd = {
+        'b.norm1.body.weight': torch.ones(C), 'b.norm2.body.weight': 1 + 0.1 * torch.randn(C, generator=g),
+        'b.attn.temperature': torch.ones(1, 1, 1), 'b.attn.qkv.weight': torch.zeros(3 * C, C, 1, 1),
+        'b.attn.qkv_dwconv.weight': torch.zeros(3 * C, 1, 3, 3), 'b.attn.project_out.weight': torch.zeros(C, C, 1, 1),
+        'b.ffn.project_in.weight': torch.randn(2 * hid, C, 1, 1, generator=g) / C ** 0.5,
+        'b.ffn.dwconv.weight': torch.randn(2 * hid, 1, 3, 3, generator=g) / 3,
+        'b.ffn.project_out.weight': torch.randn(C, hid, 1, 1, generator=g) / hid ** 0.5,
+    }
+    if ln == 2:
+        sd['b.norm1.body.bias'] = torch.zeros(C)
+        sd['b.norm2.body.bias'] = 0.1 * torch.randn(C, generator=g)
+    if bias:
+        for k, n in [('attn.qkv', 3 * C), ('attn.qkv_dwconv', 3 * C), ('attn.project_out', C), ('ffn.project_in', 2 * hid),
+                     ('ffn.dwconv', 2 * hid), ('ffn.project_out', C)]:
+            sd[f'b.{k}.bias'] = 0.1 * torch.randn(n, generator=g)
+    return sd
+
+
+@pytest.mark.parametrize('C,hid,ln,T,H,W,bias,fold', [
+    (96, 255, 1, 2, 16, 64, False, False),     # level-1 decoder shape (Hf = 255 -> 256), whole patches
+    (48, 127, 1, 1, 8, 32, False, False),
+    (96, 255, 1, 1, 13, 45, False, False),     # ragged: patches hang over the right and bottom image edges
+    (96, 255, 2, 2, 9, 33, True, False),       # WithBias LN + conv biases
+    (48, 127, 2, 1, 19, 70, False, False),
+    (96, 255, 1, 2, 16, 64, False, True),      # + the attention apply x1 = x + M_t . v folded into the prologue (per-tile M)
+    (48, 127, 1, 3, 11, 40, False, True),
+    (96, 255, 2, 2, 9, 37, True, True),        # fold with the project_out bias of the attention, WithBias LN
+    (48, 95, 2, 1, 24, 31, True, True),        # hidden width 95 -> 96: an odd number of 32-channel blocks, padded gate channels
+])
+def test_ffn2(ctx, C, hid, ln, T, H, W, bias, fold):
+    """Second-generation fused block (csrc/ira_ffn2.hip): [x1 = x + M_t . v (+ b_o)] + GDFN + residual in one kernel
+    (restormer_arch.py:127-131 as a per-tile 1x1, :88-93, :146-150) against the fp32 torch ops."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    from oracle import restormer_oracle as O
+    g = torch.Generator().manual_seed(C + hid + ln + H)
+    Hp = up32(hid)
+    x = torch.randn(T, C, H, W, generator=g) * 1.5
+    sd = _ffn_block_sd(C, hid, ln, bias, g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree' if ln == 1 else 'WithBias', bias=bias)
+    cfg.hidden = lambda d: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    ln_type = 'BiasFree' if ln == 1 else 'WithBias'
+    x1 = x
+    vd = Md = wob = None
+    NBc = up32(C) // 32
+    if fold:
+        v = r16(torch.randn(T, C, H, W, generator=g))
+        M = torch.randn(T, C, C, generator=g) / C ** 0.5
+        x1 = x + torch.einsum('toc,tchw->tohw', M, v)
+        if bias:
+            x1 = x1 + sd['b.attn.project_out.bias'].view(1, -1, 1, 1)
+            wob = dev(torch.from_numpy(arrs['b.wo_b']))
+        Mp = torch.zeros(T, NBc * 32, C)
+        Mp[:, :C] = M
+        Md = dev(split16(Mp).permute(1, 0, 2, 3, 4, 5))                 # [T][hi, lo][NB][C/16][64][8]
+        vd = dev(v.permute(0, 2, 3, 1).half())
+    xn = O.layer_norm(x1, sd['b.norm2.body.weight'], sd.get('b.norm2.body.bias'), ln_type)
+    ref = (x1 + O.feed_forward(xn, sd, 'b.ffn')).permute(0, 2, 3, 1).contiguous()
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
+    assert d['b.dw2_u'].shape == (Hp // 16, 2, 9, 16)
+    xd = dev(x.permute(0, 2, 3, 1))
+    out = torch.full(ref.shape, float('nan')).cuda()
+    rc = ctx._lib.ira_op_ffn2(ctx.handle, ptr(xd), ptr(out), ptr(vd), ptr(Md), 2 * NBc * 32 * C, ptr(wob), ln, C, ptr(d['b.pin_w']),
+                              ptr(d.get('b.pin_b')), ptr(d['b.dw2_u']), ptr(d.get('b.dw2_ub')), ptr(d['b.pout_w']), ptr(d.get('b.pout_b')),
+                              T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    got = out.cpu()
+    assert torch.isfinite(got).all(), f"{int((~torch.isfinite(got)).sum())} non-finite values"
+    # fp16 LN output / hidden / gated values inside: a few 1e-3 relative to the branch magnitude
+    err = (got - ref).abs()
+    scale = (ref - x.permute(0, 2, 3, 1)).abs().max().item()
+    assert err.max().item() <= 4e-3 * scale + 1e-4, (err.max().item(), scale, np.unravel_index(int(err.argmax()), err.shape))
+
+
+def test_ffn2_matches_generation_1(ctx):
+    """The same block through ira_op_ffn_fused (generation 1, A&S erf) and ira_op_ffn2 (Phi table): equal to table accuracy."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    C, hid, T, H, W = 96, 255, 2, 24, 64
+    g = torch.Generator().manual_seed(7)
+    Hp = up32(hid)
+    x = torch.randn(T, H, W, C, generator=g) * 1.5
+    sd = _ffn_block_sd(C, hid, 1, False, g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree')
+    cfg.hidden = lambda d: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
+    xd = dev(x)
+    o1 = torch.full(x.shape, float('nan')).cuda(); o2 = torch.full(x.shape, float('nan')).cuda()
+    rc = ctx._lib.ira_op_ffn_fused(ctx.handle, ptr(xd), ptr(o1), 1, C, ptr(d['b.pin_w']), None, ptr(d['b.dw2_w']), None, ptr(d['b.pout_w']), None, T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    rc = ctx._lib.ira_op_ffn2(ctx.handle, ptr(xd), ptr(o2), None, None, 0, None, 1, C, ptr(d['b.pin_w']), None, ptr(d['b.dw2_u']), None, ptr(d['b.pout_w']), None, T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    dlt = (o1 - o2).abs().max().item()
+    br = (o1 - xd).abs().max().item()
+    print(f"generation 1 vs 2: max |delta| {dlt:.3e} on a branch of magnitude {br:.3f}")
+    assert dlt <= 2e-5 * br + 1e-6        # same rounding points; only the GELU evaluation (1e-6) and fp32 summation order differ
+
+
 @pytest.mark.parametrize('C,ln,T,H,W,bias', [
     (48, 1, 2, 11, 40, False),      # ragged patch edges; W % 8 == 0
     (96, 1, 1, 16, 64, False),

@@ -76,6 +76,14 @@ def main():
     import re as _re
     for key in list(tr.keys()):
         m_ = _re.match(r'k_(ffn|qkv)_fused<(\d+)', key[0]) or _re.match(r'_ZN3ira11k_(ffn|qkv)_fusedILi(\d+)', key[0])
+        m2 = _re.match(r'k_ffn2<(\d+), \d+, \w+, \w+, (true|false)', key[0]) or _re.match(r'_ZN3ira6k_ffn2ILi(\d+)ELi\dELb\dELb\dELb(\d)', key[0])
+        if m2 and key in fe and key in wr:
+            patches = key[1] // 512
+            fam = 'attn_ffn_fused' if m2.group(2) in ('true', '1') else 'ffn_fused'
+            for T_, side in ((40, 512), (40, 256), (8, 512), (8, 256)):
+                if patches == T_ * ((side + 7) // 8) * ((side + 31) // 32):
+                    traffic[f'{fam}|C{m2.group(1)}|{side}x{side}|T{T_}'] = int(2.0 * 1024 * sum(fe[key]) / len(fe[key]) + 1024.0 * sum(wr[key]) / len(wr[key]))
+                    break
         if m_ and key in fe and key in wr:
             patches = key[1] // 512
             for T_, side in ((40, 512), (40, 256), (8, 512), (8, 256)):
@@ -95,8 +103,19 @@ def main():
         open(sys.argv[2], 'w').write(text)
     if len(sys.argv) > 3:
         import os
+        import datetime, glob, hashlib
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+        hsh = hashlib.sha1()
+        for f in sorted(glob.glob(os.path.join(root, 'image-restoration-agent_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'image-restoration-agent_amd', 'csrc', '*.h'))):
+            hsh.update(os.path.basename(f).encode())
+            hsh.update(open(f, 'rb').read())
+        sha = hsh.hexdigest()[:16]                 # the same digest bench.py::csrc_sha() computes: traffic is quoted only for the sources it was measured on
         old = json.load(open(sys.argv[3])) if os.path.exists(sys.argv[3]) else {}
+        if old.get('_stamp', {}).get('csrc_sha') != sha:
+            old = {}                               # measurements of other sources are dropped, not mixed
         old.update(traffic)
+        old['_stamp'] = {'csrc_sha': sha, 'when': datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ'),
+                         'how': 'tools/prof_gpu.sh: rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE as separate passes of bench.py --steps 1'}
         json.dump(old, open(sys.argv[3], 'w'), indent=1)
     print(text)
 
