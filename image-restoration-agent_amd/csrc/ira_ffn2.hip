@@ -34,6 +34,7 @@
 #include "ira_device.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -82,6 +83,32 @@ IRA_DEV void fma_mix_lo_s(float& acc, unsigned packed, float w) {
 IRA_DEV void fma_mix_hi_s(float& acc, unsigned packed, float w) {
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "s"(w));
 }
+template <int N> using IC = std::integral_constant<int, N>;
+
+// ds_read_b128 with the constant part of the address in the instruction's offset field (hipcc kept one address REGISTER per tap
+// instead: 18 loop-invariant VGPRs).  The destination is valid only after the caller's s_waitcnt lgkmcnt(0) (cdna_hip_programming.md
+// 5.7 item 1, form iii: the wait is a builtin followed by sched_barrier(0), the only consumers are asm statements after it).
+template <int OFF>
+IRA_DEV u32x4 lds_read128(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// two fp32 -> one word of two fp16 (round to nearest even)
+IRA_DEV unsigned cvt_pk_f16(float lo, float hi) {
+    typedef f16 half2v __attribute__((ext_vector_type(2)));
+    half2v t; t[0] = (f16)lo; t[1] = (f16)hi;
+    return __builtin_bit_cast(unsigned, t);
+}
+// first tap: acc = (float)half * w (no accumulator to clear beforehand)
+IRA_DEV void mul_mix_lo_s(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "s"(w));
+}
+IRA_DEV void mul_mix_hi_s(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "s"(w));
+}
 IRA_DEV void dw_tap_s(float (&acc)[8], const u32x4 v, const f32x8 w) {
     fma_mix_lo_s(acc[0], v[0], w[0]); fma_mix_hi_s(acc[1], v[0], w[1]);
     fma_mix_lo_s(acc[2], v[1], w[2]); fma_mix_hi_s(acc[3], v[1], w[3]);
@@ -102,13 +129,17 @@ IRA_DEV float gelu_gate_tab(float a, float b, const float2* tab) {
 
 }  // namespace
 
-template <int C, int LN, bool BIN, bool CB, bool FOLD>
+// DBG (diagnostic builds of ONE instantiation, selected with IRA_FFN2_DBG at launch; results are wrong or slower, never shipped on a
+// product path): 1 = unit weights are constants (no scalar loads), 2 = no vector work at all, 3 = no project_in MFMAs, 4 = s_memtime stamps
+__device__ unsigned long long g_ffn2_stamps[2][64];
+
+template <int C, int LN, bool BIN, bool CB, bool FOLD, int DBG = 0>
 __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float* __restrict__ xo, const f16* __restrict__ v,
                                               const f16* __restrict__ M, long m_stride, const float* __restrict__ wob,
                                               const f16* __restrict__ Win, const float* __restrict__ bin,
                                               const float* __restrict__ dwu, const float* __restrict__ dwub,
                                               const f16* __restrict__ Wout, const float* __restrict__ bout,
-                                              const float2* __restrict__ phitab, int T, int H, int W, int Hp) {
+                                              const float2* __restrict__ phitab, int T, int H, int W, int Hp, int stagger) {
     constexpr int KS = C / 16;            // k-steps of project_in / of the attention apply
     constexpr int NBC = (C + 31) / 32;    // 32-row blocks of project_out / of M
     constexpr size_t XN_BYTES = (size_t)NG * KS * 1024;
@@ -132,6 +163,24 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     const int NBH = Hp >> 5;              // 32-row blocks of x1 in W_in (x2's blocks follow)
     const bool isC = wave >= 4;
     const int cw = wave - 4;
+    int stamp_n = 0;
+    auto STAMP = [&]() {
+        if ((DBG == 4 || DBG == 9) && blockIdx.x == 777 && lane == 0 && (wave == 0 || wave == 4) && stamp_n < (DBG == 9 ? 32 : 64)) g_ffn2_stamps[wave >> 2][stamp_n] = __builtin_amdgcn_s_memtime();
+        ++stamp_n;
+    };
+    int sstamp_n = 32;
+    auto SLOTSTAMP = [&](int i) {
+        if (DBG == 9 && i == 5 && blockIdx.x == 777 && lane == 0 && (wave == 0 || wave == 4) && sstamp_n < 64) g_ffn2_stamps[wave >> 2][sstamp_n++] = __builtin_amdgcn_s_memtime();
+    };
+    STAMP();
+    // Phase stagger.  Every workgroup takes the same time, so without this all 256 CUs run their prologues (130 KB of x each = 33 MB
+    // at once) and then their main loops (no HBM traffic) in lockstep: the prologue is then HBM-bound chip-wide (16-19k cycles
+    // measured for what one CU alone loads in 3k) while the memory system idles for the rest of the patch.  The first block on each
+    // CU starts 0-3 quarter patch times late; its successors on that CU inherit the phase.
+    if (stagger > 0 && blockIdx.x < 256) {
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int k = 0; k < ph * stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    }
 
     // pixel of (group g, lane r): in-image flag and pixel offset inside the tile (clamped to pixel 0 when not loadable)
     auto pixel_of = [&](int g, bool& in) -> long {
@@ -143,17 +192,61 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     };
 
     // ------------------------------------------------------------------------------------------------ prologue
-    // groups of this wave: C waves their two output rows (interior groups 2cw, 2cw+1; x1 stays in acc as the residual), P waves
-    // 0-2 one group of border pixels each
-    f32x16 accA[NBC], accB[NBC];
-    const int ga = isC ? 2 * cw : NGI + wave, gb = 2 * cw + 1;
-    const bool haveA = isC || wave < NGB;
-    {
+    // (1) the 10 x 34 halo patch of x travels HBM -> LDS in whole rows (every wave instruction = 1 KB of consecutive bytes: the
+    //     per-lane "fragment shaped" loads of the first generation touched 64 cache lines per instruction and kept the texture
+    //     path busy for ~15k cycles per patch), pixel-major with a stride of C + 4 floats (conflict-free for the reads of (2));
+    // (2) every wave picks the pixels of its groups out of the staging area in accumulator layout (lane (r, h): channels
+    //     32 nb + 16 u + 8 h ..): C waves their two output rows (interior groups 2cw, 2cw+1: x1 stays in the accumulators as the
+    //     residual), P waves 0-2 one group of border pixels each;
+    // (3) x1 = x + M_t . v with M_t staged in LDS, LayerNorm, fp16 B fragments of all 11 groups -> LDS; (4) the P waves take the
+    //     fragments of their three groups into registers for the whole kernel.
+    constexpr int XS = C + 4;                                               // staging stride in floats
+    static_assert((size_t)PHW * XS * 4 <= XN_BYTES + 2 * HP_BYTES + 2 * G_BYTES, "x staging must end below the Phi table");
+    float* xs = (float*)smem;
+    // ROLE SEPARATION.  The P and C halves of the kernel are two disjoint branches from here to their ends, each with its own copy of
+    // the prologue: the register allocator then never has to keep the C waves' 96 accumulator registers reserved while it allocates
+    // the P waves' loop (it did, when the prologue was shared: the P loop ran on 160 registers and spilled).
+    auto prologue = [&](auto ISC, f32x16 (&accA)[NBC], f32x16 (&accB)[NBC]) {
+        constexpr bool isCc = decltype(ISC)::value;
+        const int ga = isCc ? 2 * cw : NGI + wave, gb = 2 * cw + 1;
+        const bool haveA = isCc || wave < NGB;
+        constexpr int PPR = PW * C / 4;                                     // 16-byte pieces per halo row
+        constexpr int NPIECE = PH * PPR, NIT = (NPIECE + 511) / 512;
+        f32x4 piece[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = it * 512 + tid;
+            const int hy = id / PPR, wi = id - hy * PPR, hx = wi / (C / 4);
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = id < NPIECE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* src = xt + ((long)(ok ? yy : 0) * W + (ok ? x0 - 1 : 0)) * C + (ok ? wi * 4 : 0);
+            piece[it] = *(const f32x4*)src;
+        }
         half8 vA[KS], vB[KS];
-        auto load_group = [&](f32x16 (&acc)[NBC], half8 (&vb)[KS], int g) {
+        if (FOLD) {
             bool in;
-            const long pix = pixel_of(g, in);
-            const float* src = xt + pix * C;
+            if (haveA) {
+                const long pix = pixel_of(ga, in);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) vA[s] = *(const half8*)(vt + pix * C + 16 * s + 8 * h);
+            }
+            if (isCc) {
+                const long pix = pixel_of(gb, in);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) vB[s] = *(const half8*)(vt + pix * C + 16 * s + 8 * h);
+            }
+        }
+        ((f32x4*)tab)[tid] = ((const f32x4*)phitab)[tid];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = it * 512 + tid;
+            const int hy = id / PPR, wi = id - hy * PPR, hx = wi / (C / 4), ch = wi - hx * (C / 4);
+            if (id < NPIECE) *(f32x4*)(xs + (long)(hy * PW + hx) * XS + 4 * ch) = piece[it];
+        }
+        __syncthreads();                                                    // (1) done
+        auto take_group = [&](f32x16 (&acc)[NBC], int g) {
+            const int q = group_q(g, r);
+            const float* src = xs + (long)(q < 0 ? 0 : q) * XS;
 #pragma unroll
             for (int nb = 0; nb < NBC; ++nb)
 #pragma unroll
@@ -167,20 +260,15 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                         for (int e = 0; e < 8; ++e) acc[nb][8 * u + e] = 0.f;
                     }
                 }
-            if (FOLD) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) vb[s] = *(const half8*)(vt + pix * C + 16 * s + 8 * h);
-            }
         };
-        if (haveA) load_group(accA, vA, ga);
-        if (isC) load_group(accB, vB, gb);
-        // stage the tile's attention matrix and the Phi table (LDS writes of all 8 waves; the x / v loads above are in flight)
+        if (haveA) take_group(accA, ga);
+        if (isCc) take_group(accB, gb);
+        __syncthreads();                                                    // (2) done: the staging area is dead
         if (FOLD) {
             const half8* Mg = (const half8*)(M + (long)t * m_stride);
             for (int i = tid; i < 2 * NBC * KS * 64; i += 512) Mlds[i] = Mg[i];
+            __syncthreads();
         }
-        ((f32x4*)tab)[tid] = ((const f32x4*)phitab)[tid];
-        __syncthreads();
 
         auto fold_ln_store = [&](f32x16 (&acc)[NBC], const half8 (&vb)[KS], int g) {
             if (FOLD) {
@@ -224,8 +312,8 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             }
         };
         if (haveA) fold_ln_store(accA, vA, ga);
-        if (isC) fold_ln_store(accB, vB, gb);
-    }
+        if (isCc) fold_ln_store(accB, vB, gb);
+    };
 
     // W_in fragment of chunk c for this lane: MFMA rows 0-15 = x1 channels 16c.., rows 16-31 = the gate channels 16c.. (see header)
     const long win_lo = (long)(2 * NBH) * KS * 512;
@@ -233,26 +321,26 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         const int blk = ((r < 16) ? 0 : NBH) + (c >> 1);
         return Win + ((long)blk * KS * 64 + 16 * (c & 1) + (r & 15) + 32 * h) * 8;
     };
-    half8 fh[KS], fl[KS];
-    auto load_win = [&](int c) {
+    // weight fragments are requested a whole interval ahead into the other register set (all CUs fetch their next chunk at about the
+    // same moment: the L2 answers such a burst in ~1k cycles, more than the tail of an interval hides)
+    half8 fwh[2][KS], fwl[2][KS];
+    auto load_win = [&](int c, int set) {
         const f16* p = win_ptr(c);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { fh[s] = *(const half8*)(p + s * 512); fl[s] = *(const half8*)(p + win_lo + s * 512); }
+        for (int s = 0; s < KS; ++s) { fwh[set][s] = *(const half8*)(p + s * 512); fwl[set][s] = *(const half8*)(p + win_lo + s * 512); }
     };
-    if (!isC) load_win(0);
     // W_out fragments of chunk c (C waves)
     const int KTO = NCH;
     const long wout_lo = (long)NBC * KTO * 512;
-    half8 woh[NBC], wol[NBC];
-    auto load_wout = [&](int c) {
+    half8 woh2[2][NBC], wol2[2][NBC];
+    auto load_wout = [&](int c, int set) {
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb) {
-            woh[nb] = *(const half8*)(Wout + (((long)nb * KTO + c) * 64 + lane) * 8);
-            wol[nb] = *(const half8*)(Wout + wout_lo + (((long)nb * KTO + c) * 64 + lane) * 8);
+            woh2[set][nb] = *(const half8*)(Wout + (((long)nb * KTO + c) * 64 + lane) * 8);
+            wol2[set][nb] = *(const half8*)(Wout + wout_lo + (((long)nb * KTO + c) * 64 + lane) * 8);
         }
     };
-    __syncthreads();        // xn fragments complete; M no longer read: its LDS region becomes the hp / g buffers
-
+    // (the two barrier-separated halves of "(3) done" sit in the role branches below)
     // ------------------------------------------------------------------------------------------------ pipeline pieces
     // An interval is nine SLOTS, one per depthwise tap.  Slot t of a wave: wait for the operands requested in slot t-1 (the only
     // wait in the loop: scalar loads return out of order, so it has to be lgkmcnt(0), and it must come BEFORE the next requests),
@@ -269,41 +357,82 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         (void)pixel_of(g < NG ? g : 0, pin[gi]);
     }
     const int urp = wave & 3, uoc = wave >> 2;
-    f32x16 uw[2];                          // tap weights: [0..7] x1 channels, [8..15] gate channels (SGPRs)
-    u32x4 uv1[2], uv2[2];                  // hp values of the tap: x1 octet, gate octet
+    // The unit's 18 HALF TAPS (tap k of the 8 x1 channels for k < 9, tap k - 9 of the 8 gate channels after that) are walked two per
+    // slot: x1 is complete in the middle of slot 4, its eight Phi look-ups are issued in slot 5 and finished in slot 7, all in the
+    // shadow of the gate's FMAs (and, in P, of the MFMAs) - only the last multiply and the fp16 pack are left behind slot 8.
+    f32x16 uw[2];                          // the slot's weights: [0..7] first half tap, [8..15] second half tap (SGPRs)
+    u32x4 uva[2], uvb[2];                  // hp values of the two half taps (8 fp16 each)
     float a1[8], a2[8];
-    half8 bq[2][KPS];
-    auto unit_request = [&](int c, int tap, int slot) {
-        const f16* hb = hpbuf + (size_t)(c & 1) * PHW * HPS + ((long)(2 * urp + h + tap / 3) * PW + r + tap % 3) * HPS + 8 * uoc;
-        uv1[slot] = *(const u32x4*)hb;
-        uv2[slot] = *(const u32x4*)(hb + 16);
-        uw[slot] = sload16(dwu + ((long)(c * 2 + uoc) * 9 + tap) * 16);
+    half8 bq[2][KPS];                      // P: B fragments of this slot's / the next slot's MFMAs (from the xn region of LDS)
+    // LDS byte address of this lane's pixel / octet in hp buffer 0 (all of this kernel's LDS is dynamic: smem starts at LDS offset 0)
+    const unsigned hb_lane = (unsigned)XN_BYTES + (unsigned)((((2 * urp + h) * PW + r) * HPS + 8 * uoc) * 2);
+    auto unit_request = [&](unsigned hbase, const float* wunit, auto TC, int slot) {       // operands of slot t (half taps 2t, 2t+1)
+        constexpr int t = decltype(TC)::value;
+        constexpr int k0 = 2 * t, k1 = 2 * t + 1, tap0 = k0 < 9 ? k0 : k0 - 9, tap1 = k1 < 9 ? k1 : k1 - 9;
+        constexpr int off0 = ((tap0 / 3) * PW + tap0 % 3) * HPS * 2 + (k0 < 9 ? 0 : 32), off1 = ((tap1 / 3) * PW + tap1 % 3) * HPS * 2 + (k1 < 9 ? 0 : 32);
+        if (DBG == 5) { uva[slot] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; uvb[slot] = uva[slot]; }
+        else { uva[slot] = lds_read128<off0>(hbase); uvb[slot] = lds_read128<off1>(hbase); }
+        if (DBG == 1) { for (int e = 0; e < 16; ++e) uw[slot][e] = 0.01f * (e + 1); }
+        else uw[slot] = sload16(wunit + 16 * t);
     };
+    f32x16 ubias;
     auto unit_init = [&](int c) {
-        if (CB) {
-            const f32x16 bb = sload16(dwub + (long)(c * 2 + uoc) * 16);
+        if (CB) ubias = sload16(dwub + (long)(c * 2 + uoc) * 16);
+    };
+    // quarter q (0-3) of slot t's 16 FMAs: q < 2 first half tap, q >= 2 second
+    auto unit_fma4 = [&](int slot, int q, int t) {
+        const int k = 2 * t + (q >> 1);                      // half tap
+        float* acc = (k < 9 ? a1 : a2) + 4 * (q & 1);
+        const u32x4& vv = (q < 2) ? uva[slot] : uvb[slot];
+        const unsigned va = vv[2 * (q & 1)], vb = vv[2 * (q & 1) + 1];
+        const int w0 = 8 * (q >> 1) + 4 * (q & 1);
+        if (k == 0 || k == 9) {        // first tap of x1 / of the gate: a product (+ bias), not an accumulation
+            if (CB) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a1[e] = bb[e]; a2[e] = bb[8 + e]; }
+                for (int e = 0; e < 4; ++e) acc[e] = ubias[(k == 9 ? 8 : 0) + 4 * (q & 1) + e];
+                fma_mix_lo_s(acc[0], va, uw[slot][w0 + 0]); fma_mix_hi_s(acc[1], va, uw[slot][w0 + 1]);
+                fma_mix_lo_s(acc[2], vb, uw[slot][w0 + 2]); fma_mix_hi_s(acc[3], vb, uw[slot][w0 + 3]);
+            } else {
+                mul_mix_lo_s(acc[0], va, uw[slot][w0 + 0]); mul_mix_hi_s(acc[1], va, uw[slot][w0 + 1]);
+                mul_mix_lo_s(acc[2], vb, uw[slot][w0 + 2]); mul_mix_hi_s(acc[3], vb, uw[slot][w0 + 3]);
+            }
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+            fma_mix_lo_s(acc[0], va, uw[slot][w0 + 0]); fma_mix_hi_s(acc[1], va, uw[slot][w0 + 1]);
+            fma_mix_lo_s(acc[2], vb, uw[slot][w0 + 2]); fma_mix_hi_s(acc[3], vb, uw[slot][w0 + 3]);
         }
     };
-    // quarter q (0-3) of a tap's 16 FMAs
-    auto unit_fma4 = [&](int slot, int q) {
-        float* acc = (q < 2) ? a1 + 4 * q : a2 + 4 * (q - 2);
-        const unsigned va = (q < 2) ? uv1[slot][2 * q] : uv2[slot][2 * (q - 2)];
-        const unsigned vb = (q < 2) ? uv1[slot][2 * q + 1] : uv2[slot][2 * (q - 2) + 1];
-        fma_mix_lo_s(acc[0], va, uw[slot][4 * q + 0]); fma_mix_hi_s(acc[1], va, uw[slot][4 * q + 1]);
-        fma_mix_lo_s(acc[2], vb, uw[slot][4 * q + 2]); fma_mix_hi_s(acc[3], vb, uw[slot][4 * q + 3]);
+    // GELU gate, four channels at a time: (a) index / fraction / ds_read_b64 of (Phi, slope) in slots 5 and 6; (b) Phi(|a1|) one slot
+    // later; (c) after slot 8: gate, pack, store
+    float ft[8]; float2 fe[4];
+    auto unit_gelu_a = [&](int e0) {                 // look-ups of channels e0 .. e0 + 3
+        if (DBG == 6) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float tt = fminf(fabsf(a1[e0 + e]) * ((float)NTAB / TAB_RANGE), (float)NTAB - 0.004f);
+            ft[e0 + e] = __builtin_amdgcn_fractf(tt);
+            fe[e] = tab[(int)tt];
+        }
+    };
+    auto unit_gelu_b = [&](int e0) {
+        if (DBG == 6) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ft[e0 + e] = fmaf(ft[e0 + e], fe[e].y, fe[e].x);       // Phi(|a1|)
     };
     auto unit_finish = [&](int c) {
-        half8 gg;
+        u32x4 gg;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gg[e] = (f16)gelu_gate_tab(a1[e], a2[e], tab);
-        gbuf[(((c & 1) * 4 + urp) * 2 + h) * 64 + r + 32 * uoc] = gg;
+        for (int j = 0; j < 4; ++j) {
+            float g0, g1;
+            if (DBG == 6) { g0 = a1[2 * j] * a2[2 * j]; g1 = a1[2 * j + 1] * a2[2 * j + 1]; }
+            else {
+                g0 = fmaf(fabsf(a1[2 * j]), ft[2 * j], fminf(a1[2 * j], 0.f)) * a2[2 * j];
+                g1 = fmaf(fabsf(a1[2 * j + 1]), ft[2 * j + 1], fminf(a1[2 * j + 1], 0.f)) * a2[2 * j + 1];
+            }
+            gg[j] = cvt_pk_f16(g0, g1);
+        }
+        *(u32x4*)&gbuf[(((c & 1) * 4 + urp) * 2 + h) * 64 + r + 32 * uoc] = gg;
     };
-#define IRA_PIN() __builtin_amdgcn_sched_barrier(0)
+#define IRA_PIN() do { if (DBG != 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define IRA_WAIT_LGKM() __builtin_amdgcn_s_waitcnt(0xC07F)
 
     // ------------------------------------------------------------------------------------------------ main loop
@@ -311,27 +440,63 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // The (produce, unit) / (unit, consume) activity of an interval is a compile-time property of its body: the first and last
     // intervals are peeled so that the steady-state body carries no branches.
     if (!isC) {
-        f32x16 acc;
-        auto interval = [&](auto PRc, auto UNc, int i) {
-            constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value;
+        {
+            f32x16 accT[NBC];                      // P: x1 of one group of border pixels, only to LayerNorm it
+            prologue(std::false_type{}, accT, accT);
+        }
+        load_win(0, 0);
+        STAMP();
+        __syncthreads();    // (3) done: xn fragments complete; M no longer read: its LDS region becomes the hp / g buffers
+        STAMP();
+        f32x16 accp[1];
+        auto write_out = [&](const f32x16& acc, f16* hp, int gi) {
+            if (DBG == 7) { asm volatile("" :: "v"(acc)); return; }
+            const int q = pq[gi];
+            if (q >= 0) {
+                // convert in pairs (v_cvt_pk_f16_f32, round to nearest even), then zero whole words where the pixel lies outside the
+                // image (the zero padding of the depthwise conv): 8 + 8 vector instructions instead of 16 + 16 + 8
+                const unsigned keep = pin[gi] ? 0xffffffffu : 0u;
+                u32x4 o1, o2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o1[j] = cvt_pk_f16(acc[2 * j], acc[2 * j + 1]) & keep;
+                    o2[j] = cvt_pk_f16(acc[8 + 2 * j], acc[8 + 2 * j + 1]) & keep;
+                }
+                *(u32x4*)(hp + (long)q * HPS + 8 * h) = o1;
+                *(u32x4*)(hp + (long)q * HPS + 16 + 8 * h) = o2;
+            }
+        };
+        auto interval = [&](auto PRc, auto UNc, auto PARc, int i) {
+            constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value && DBG != 2;
+            constexpr int par = decltype(PARc)::value;                 // i & 1: the weight register set of this interval
+            if (pr && i + 1 < NCH) load_win(i + 1, par ^ 1);
             f16* hp = hpbuf + (size_t)(i & 1) * PHW * HPS;
-            if (un) { unit_init(i - 1); unit_request(i - 1, 0, 0); }
+            const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;       // the unit reads chunk i-1's buffer
+            const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
+            if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
             if (pr) {
 #pragma unroll
                 for (int k = 0; k < KPS; ++k) bq[0][k] = xnl[(wave * KS + k) * 64 + lane];
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int gi = t / 3, sl = t & 1;
-                const bool pv = pr && (gi < 2 || wave < 3);            // wave 3 has two pixel groups only (wave-uniform)
+            auto slot = [&](auto TC) {
+                constexpr int t = decltype(TC)::value, gi = t / 3, sl = t & 1;
+                // wave 3 has two pixel groups only; it runs a third, discarded one (group 11 = whatever follows the xn fragments in LDS;
+                // pq = -1 skips its write-out) rather than branch around it: SIMD 3 then carries the same 48 MFMAs per chunk as the others
+                constexpr bool pv = pr;
+                f32x16& acc = accp[0];
+                SLOTSTAMP(i);
                 IRA_WAIT_LGKM();
+                SLOTSTAMP(i);
                 IRA_PIN();
-                if (un && t < 8) unit_request(i - 1, t + 1, sl ^ 1);
-                if (pr && t < 8 && ((t + 1) / 3 < 2 || wave < 3)) {
+                if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
+                if (pr && t < 8) {
 #pragma unroll
                     for (int k = 0; k < KPS; ++k) bq[sl ^ 1][k] = xnl[((wave + 4 * ((t + 1) / 3)) * KS + KPS * ((t + 1) % 3) + k) * 64 + lane];
                 }
                 IRA_PIN();
+                if (un && t == 5) unit_gelu_a(0);
+                if (un && t == 6) { unit_gelu_b(0); unit_gelu_a(4); }
+                if (un && t == 7) unit_gelu_b(4);
                 if (pv) {
                     if (t % 3 == 0) {
 #pragma unroll
@@ -343,71 +508,91 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
 #pragma unroll
                     for (int k = 0; k < KPS; ++k) {
                         const int ks = KPS * (t % 3) + k;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], bq[sl][k], acc, 0, 0, 0);
-                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k : 0); if (KPS == 1) unit_fma4(sl, 1); }
+                        if (DBG != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[par][ks], bq[sl][k], acc, 0, 0, 0);
+                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k : 0, t); if (KPS == 1) unit_fma4(sl, 1, t); }
                         IRA_PIN();
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], bq[sl][k], acc, 0, 0, 0);
-                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k + 1 : 2); if (KPS == 1) unit_fma4(sl, 3); }
+                        if (DBG != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[par][ks], bq[sl][k], acc, 0, 0, 0);
+                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k + 1 : 2, t); if (KPS == 1) unit_fma4(sl, 3, t); }
                         IRA_PIN();
                     }
-                    if (t % 3 == 2) {
-                        const bool in = pin[gi];
-                        const int q = pq[gi];
-                        if (q >= 0) {
-                            half8 o1, o2;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { o1[e] = in ? (f16)acc[e] : (f16)0.f; o2[e] = in ? (f16)acc[8 + e] : (f16)0.f; }   // zero padding of the dwconv
-                            *(half8*)(hp + (long)q * HPS + 8 * h) = o1;
-                            *(half8*)(hp + (long)q * HPS + 16 + 8 * h) = o2;
-                        }
-                    }
-                } else if (un) {
-                    unit_fma4(sl, 0); unit_fma4(sl, 1); unit_fma4(sl, 2); unit_fma4(sl, 3);
+                    if (t % 3 == 2) write_out(acc, hp, gi);
+                } else {
+                    if (un) { unit_fma4(sl, 0, t); unit_fma4(sl, 1, t); unit_fma4(sl, 2, t); unit_fma4(sl, 3, t); }
                 }
-            }
-            if (pr && i + 1 < NCH) load_win(i + 1);
+            };
+            slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{}); slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{}); slot(IC<8>{});
+            STAMP();
             if (un) unit_finish(i - 1);
+            STAMP();
             lds_barrier();
+            STAMP();
         };
-        interval(std::true_type{}, std::false_type{}, 0);
-        for (int i = 1; i < NCH; ++i) interval(std::true_type{}, std::true_type{}, i);
-        interval(std::false_type{}, std::true_type{}, NCH);
+        using I0 = IC<0>; using I1 = IC<1>;
+        interval(std::true_type{}, std::false_type{}, I0{}, 0);
+        for (int i = 1; i + 1 < NCH; i += 2) {                          // NCH is even (Hp % 32 == 0): intervals 1 .. NCH-2 in pairs
+            interval(std::true_type{}, std::true_type{}, I1{}, i);
+            interval(std::true_type{}, std::true_type{}, I0{}, i + 1);
+        }
+        interval(std::true_type{}, std::true_type{}, I1{}, NCH - 1);
+        interval(std::false_type{}, std::true_type{}, I0{}, NCH);
         return;
     }
+    f32x16 accA[NBC], accB[NBC];                   // C: x1 of this wave's two rows = the residual the block's output accumulates on
+    prologue(std::true_type{}, accA, accB);
+    STAMP();
+    __syncthreads();        // (3) done (see the P branch)
+    STAMP();
     half8 fA, fB;
-    auto cinterval = [&](auto UNc, auto COc, int i) {
-        constexpr bool un = decltype(UNc)::value, co = decltype(COc)::value;
-        if (un) { unit_init(i - 1); unit_request(i - 1, 0, 0); }
+    auto cinterval = [&](auto UNc, auto COc, auto PARc, int i) {
+        constexpr bool un_ = decltype(UNc)::value, un = un_ && DBG != 2, co = decltype(COc)::value;
+        constexpr int par = decltype(PARc)::value;                     // (i - 2) & 1 = i & 1: the weight register set chunk i - 2 was loaded into
+        if (un_) load_wout(i - 1, par ^ 1);                            // chunk i - 1 is consumed in the next interval
+        const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;
+        const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
+        if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
         if (co) {
             fA = gbuf[((((i - 2) & 1) * 4 + cw) * 2 + 0) * 64 + lane];
             fB = gbuf[((((i - 2) & 1) * 4 + cw) * 2 + 1) * 64 + lane];
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            constexpr int dummy = 0; (void)dummy;
-            const int sl = t & 1, nb = (t >> 1) < NBC ? (t >> 1) : 0;
-            const bool cv = co && (t >> 1) < NBC;
+        auto slot = [&](auto TC) {
+            constexpr int t = decltype(TC)::value, sl = t & 1, nb = (t >> 1) < NBC ? (t >> 1) : 0;
+            constexpr bool cv = co && (t >> 1) < NBC;
+            SLOTSTAMP(i);
             IRA_WAIT_LGKM();
+            SLOTSTAMP(i);
             IRA_PIN();
-            if (un && t < 8) unit_request(i - 1, t + 1, sl ^ 1);
+            if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
             IRA_PIN();
-            if (cv) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh[nb], fB, accB[nb], 0, 0, 0);
-                      else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh[nb], fA, accA[nb], 0, 0, 0); }
-            if (un) { unit_fma4(sl, 0); unit_fma4(sl, 1); }
+            if (un && t == 5) unit_gelu_a(0);
+            if (un && t == 6) { unit_gelu_b(0); unit_gelu_a(4); }
+            if (un && t == 7) unit_gelu_b(4);
+            if (cv) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh2[par][nb], fB, accB[nb], 0, 0, 0);
+                      else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh2[par][nb], fA, accA[nb], 0, 0, 0); }
+            if (un) { unit_fma4(sl, 0, t); unit_fma4(sl, 1, t); }
             IRA_PIN();
-            if (cv) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol[nb], fB, accB[nb], 0, 0, 0);
-                      else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol[nb], fA, accA[nb], 0, 0, 0); }
-            if (un) { unit_fma4(sl, 2); unit_fma4(sl, 3); }
+            if (cv) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fB, accB[nb], 0, 0, 0);
+                      else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fA, accA[nb], 0, 0, 0); }
+            if (un) { unit_fma4(sl, 2, t); unit_fma4(sl, 3, t); }
             IRA_PIN();
-        }
-        if (un) load_wout(i - 1);                           // consumed in the next interval
+        };
+        slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{}); slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{}); slot(IC<8>{});
         if (un) unit_finish(i - 1);
-        if (un) lds_barrier();
+        STAMP();
+        if (un_) lds_barrier();
+        STAMP();
     };
     lds_barrier();                                          // the barrier of interval 0 (P only)
-    cinterval(std::true_type{}, std::false_type{}, 1);
-    for (int i = 2; i <= NCH; ++i) cinterval(std::true_type{}, std::true_type{}, i);
-    cinterval(std::false_type{}, std::true_type{}, NCH + 1);
+    STAMP();
+    {
+        using I0 = IC<0>; using I1 = IC<1>;
+        cinterval(std::true_type{}, std::false_type{}, I1{}, 1);
+        for (int i = 2; i < NCH; i += 2) {
+            cinterval(std::true_type{}, std::true_type{}, I0{}, i);
+            cinterval(std::true_type{}, std::true_type{}, I1{}, i + 1);
+        }
+        cinterval(std::true_type{}, std::true_type{}, I0{}, NCH);
+        cinterval(std::false_type{}, std::true_type{}, I1{}, NCH + 1);
+    }
 #undef IRA_PIN
 #undef IRA_WAIT_LGKM
 
@@ -466,6 +651,10 @@ static hipError_t phi_table(const float2** out) {
     return hipSuccess;
 }
 
+extern "C" int ira_debug_ffn2_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffn2_stamps), sizeof(unsigned long long) * 128);
+}
+
 bool ffn2_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0; }
 
 template <int C, int LN, bool BIN, bool CB, bool FOLD>
@@ -479,8 +668,23 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD>, LDS, attr_done); e != hipSuccess) return e;
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    static const int stagger_env = getenv("IRA_FFN2_STAGGER") ? atoi(getenv("IRA_FFN2_STAGGER")) : 3;   // s_sleep(127) units per phase step
+    const int stagger = nblk >= 1024 ? stagger_env : 0;          // only where a CU runs several patches
+    if constexpr (C == 96 && LN == 1 && !BIN && !CB && !FOLD) {
+        static const int dbg = getenv("IRA_FFN2_DBG") ? atoi(getenv("IRA_FFN2_DBG")) : 0;
+#define IRA_DBG_LAUNCH(D_)                                                                                                                     \
+    if (dbg == D_) {                                                                                                                            \
+        static std::atomic<uint64_t> ad{0};                                                                                                     \
+        if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD, D_>, LDS, ad); e != hipSuccess) return e;                \
+        hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD, D_>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, \
+                           dww, dwb, Wout, bout, tab, T, H, W, Hp, stagger);                                                                    \
+        return hipGetLastError();                                                                                                               \
+    }
+        IRA_DBG_LAUNCH(1) IRA_DBG_LAUNCH(2) IRA_DBG_LAUNCH(3) IRA_DBG_LAUNCH(4) IRA_DBG_LAUNCH(5) IRA_DBG_LAUNCH(6) IRA_DBG_LAUNCH(7) IRA_DBG_LAUNCH(8) IRA_DBG_LAUNCH(9)
+#undef IRA_DBG_LAUNCH
+    }
     hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
-                       Wout, bout, tab, T, H, W, Hp);
+                       Wout, bout, tab, T, H, W, Hp, stagger);
     return hipGetLastError();
 }
 

@@ -86,11 +86,13 @@ def _dw_pack(w: np.ndarray) -> np.ndarray:
 
 
 def _dw_unit_pack(w9: np.ndarray, hp: int) -> np.ndarray:
-    """[9][2hp] tap-major depthwise weights -> [hp/16][2][9][16] for csrc/ira_ffn2.hip: everything ONE vector-work unit (16-channel
-    chunk c of the GDFN hidden width, channel octet oc) needs is 144 contiguous floats, per tap [x1 channels 16c+8oc.. (8) |
-    gate channels hp+16c+8oc.. (8)], so the kernel fetches a tap with one s_load_dwordx16 at an immediate offset."""
+    """[9][2hp] tap-major depthwise weights -> [hp/16][2][18][8] for csrc/ira_ffn2.hip: everything ONE vector-work unit (16-channel
+    chunk c of the GDFN hidden width, channel octet oc) needs is 144 contiguous floats: the nine taps of its 8 x1 channels
+    (16c + 8oc ..), then the nine taps of its 8 gate channels (hp + 16c + 8oc ..).  The kernel walks them two "half taps" (16 floats,
+    one s_load_dwordx16 at an immediate offset) per slot, x1 first: GELU needs x1 only, so its table look-ups run under the gate's
+    FMAs."""
     a = w9.reshape(9, 2, hp // 16, 2, 8)                          # [tap][x1|x2][c][oc][e]
-    return np.ascontiguousarray(a.transpose(2, 3, 0, 1, 4).reshape(hp // 16, 2, 9, 16).astype(np.float32))
+    return np.ascontiguousarray(a.transpose(2, 3, 1, 0, 4).reshape(hp // 16, 2, 18, 8).astype(np.float32))
 
 
 def _dw_unit_bias(b: np.ndarray, hp: int) -> np.ndarray:

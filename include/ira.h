@@ -336,7 +336,7 @@ int ira_op_ffn_fused(ira_model_t* m, const float* x_dev, float* x_out_dev, int l
 /* Fused attention apply + GDFN block, second generation (csrc/ira_ffn2.hip), one kernel; C in {48, 96}:
  *   x1 = x + M_t . v (+ wo_b)   (restormer_arch.py:127-131 re-associated as ira_op_attn_mix does),   x_out = x1 + ffn(LN(x1))  (:88-93,:149).
  * v fp16 NHWC (T,H,W,C) and M (the fp16 hi/lo fragment-major matrices ira_op_attn_mix writes, m_tile_stride halfs per tile) may both
- * be NULL: x1 = x, the plain GDFN block.  dwu fp32 [Hp/16][2][9][16] = the depthwise weights per (16-channel chunk, octet) unit
+ * be NULL: x1 = x, the plain GDFN block.  dwu fp32 [Hp/16][2][18][8] = the depthwise weights per (16-channel chunk, octet) unit (x1 taps, then gate taps)
  * (ira_amd/pack.py::_dw_unit_pack), dwub fp32 [Hp/16][2][16] or NULL; the other arguments as ira_op_ffn_fused.  x_out must not alias x. */
 int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void* v_dev, const void* M_dev, long m_tile_stride,
                 const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev, const float* dwu_dev,

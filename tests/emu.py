@@ -20,15 +20,18 @@ def r16(t):
 class Contract:
     """Which storage points round to fp16.  ``off`` = set of tags left un-rounded (ablations)."""
 
-    def __init__(self, res_fp16=True, act_fp16=True, off=(), only=None):
+    def __init__(self, res_fp16=True, act_fp16=True, off=(), only=None, on=()):
         self.res_fp16 = res_fp16
         self.act_fp16 = act_fp16
         self.off = set(off)
         self.only = None if only is None else set(only)
+        self.on = set(on)
 
     def _on(self, tag):
         if self.only is not None:
             return tag in self.only
+        if tag.startswith('w_') and 'w' in self.off and tag not in self.on:
+            return False                     # the per-layer weight tags follow the global 'w' switch unless switched on by name
         return tag not in self.off
 
     def res(self, t, tag='res'):
@@ -54,10 +57,10 @@ def ln_core(x, ln_type):
     return x * rstd if ln_type == 'BiasFree' else (x - mu) * rstd
 
 
-def fold_ln(w, lnw, lnb, ct):
+def fold_ln(w, lnw, lnb, ct, tag='w'):
     """conv1x1(LN(x)) = conv1x1_{W*diag(lnw)}(core(x)) + W@lnb."""
     w2 = w[:, :, 0, 0]
-    wf = ct.w(w2 * lnw.view(1, -1))
+    wf = ct.w(w2 * lnw.view(1, -1), tag)
     bias = (w2 @ lnb) if lnb is not None else None
     return wf, bias
 
@@ -88,7 +91,7 @@ def attention_mix(q, k, temperature, wo, heads):
 def block(x, sd, p, heads, ln_type, ct: Contract):
     c = x.shape[1]
     lnb1 = sd.get(f'{p}.norm1.body.bias')
-    wq, bq = fold_ln(sd[f'{p}.attn.qkv.weight'], sd[f'{p}.norm1.body.weight'], lnb1, ct)
+    wq, bq = fold_ln(sd[f'{p}.attn.qkv.weight'], sd[f'{p}.norm1.body.weight'], lnb1, ct, 'w_qkv')
     xn = ct.act(ln_core(x, ln_type), 'xn1')
     qkv_pre = ct.act(conv1x1(xn, wq, bq), 'qkv_pre')
     qkv = F.conv2d(qkv_pre, ct.w(sd[f'{p}.attn.qkv_dwconv.weight'], 'dw1w'), padding=1, groups=3 * c)
@@ -98,13 +101,13 @@ def block(x, sd, p, heads, ln_type, ct: Contract):
     x = ct.res(x + torch.einsum('bchw,boc->bohw', v, m), 'res_attn')
 
     lnb2 = sd.get(f'{p}.norm2.body.bias')
-    wi, bi = fold_ln(sd[f'{p}.ffn.project_in.weight'], sd[f'{p}.norm2.body.weight'], lnb2, ct)
+    wi, bi = fold_ln(sd[f'{p}.ffn.project_in.weight'], sd[f'{p}.norm2.body.weight'], lnb2, ct, 'w_pin')
     xn = ct.act(ln_core(x, ln_type), 'xn2')
     hp = ct.act(conv1x1(xn, wi, bi), 'hp')
     hd = F.conv2d(hp, ct.w(sd[f'{p}.ffn.dwconv.weight'], 'dw2w'), padding=1, groups=hp.shape[1])
     h1, h2 = hd.chunk(2, dim=1)
     g = ct.act(F.gelu(h1) * h2, 'g')
-    x = ct.res(x + conv1x1(g, ct.w(sd[f'{p}.ffn.project_out.weight'][:, :, 0, 0])), 'res_ffn')
+    x = ct.res(x + conv1x1(g, ct.w(sd[f'{p}.ffn.project_out.weight'][:, :, 0, 0], 'w_pout')), 'res_ffn')
     return x
 
 

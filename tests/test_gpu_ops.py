@@ -431,7 +431,7 @@ def test_ffn2(ctx, C, hid, ln, T, H, W, bias, fold):
     xn = O.layer_norm(x1, sd['b.norm2.body.weight'], sd.get('b.norm2.body.bias'), ln_type)
     ref = (x1 + O.feed_forward(xn, sd, 'b.ffn')).permute(0, 2, 3, 1).contiguous()
     d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
-    assert d['b.dw2_u'].shape == (Hp // 16, 2, 9, 16)
+    assert d['b.dw2_u'].shape == (Hp // 16, 2, 18, 8)
     xd = dev(x.permute(0, 2, 3, 1))
     out = torch.full(ref.shape, float('nan')).cuda()
     rc = ctx._lib.ira_op_ffn2(ctx.handle, ptr(xd), ptr(out), ptr(vd), ptr(Md), 2 * NBc * 32 * C, ptr(wob), ln, C, ptr(d['b.pin_w']),
@@ -469,7 +469,9 @@ def test_ffn2_matches_generation_1(ctx):
     dlt = (o1 - o2).abs().max().item()
     br = (o1 - xd).abs().max().item()
     print(f"generation 1 vs 2: max |delta| {dlt:.3e} on a branch of magnitude {br:.3f}")
-    assert dlt <= 2e-5 * br + 1e-6        # same rounding points; only the GELU evaluation (1e-6) and fp32 summation order differ
+    # same rounding points, but the fp32 sums feeding them are formed in another order (and GELU differs by 1e-6): a hidden value next to
+    # a rounding boundary lands on the other fp16 neighbour (2^-11 relative), which is what the two outputs differ by
+    assert dlt <= 5e-4 * br + 1e-6
 
 
 @pytest.mark.parametrize('C,ln,T,H,W,bias', [

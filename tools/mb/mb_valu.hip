@@ -65,6 +65,29 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, i
             REP16(asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\tv_fma_f32 %3, %3, %9, %3\n\tv_fma_f32 %4, %4, %9, %4\n\tv_fma_f32 %5, %5, %9, %5\n\t"
                                "v_fma_f32 %6, %6, %9, %6\n\tv_fma_f32 %7, %7, %9, %7\n\tv_fma_f32 %8, %8, %9, %8"
                                : "+v"(acc) : "v"(fa), "v"(fb), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(w));)
+        } else if constexpr (MODE == 11 || MODE == 12) {
+            // the fused-GDFN slot: waves 0-3 ("P") a dependent chain of 4 MFMAs with 4 FMAs behind each; waves 4+ ("C") 2 dependent MFMAs + 16 FMAs
+            // MODE 12: P uses two alternating accumulators
+            if (__builtin_amdgcn_readfirstlane(wave) < 4) {
+                f32x16 acc2 = acc;
+                REP4(REP4(asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\tv_fma_f32 %3, %3, %7, %3\n\tv_fma_f32 %4, %4, %7, %4\n\tv_fma_f32 %5, %5, %7, %5\n\tv_fma_f32 %6, %6, %7, %6"
+                                   : "+v"(acc) : "v"(fa), "v"(fb), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(w));
+                          if (MODE == 12) { f32x16 tmp = acc; acc = acc2; acc2 = tmp; }))
+                acc += acc2;
+            } else {
+                REP4(asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb));
+                     for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(w));
+                     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb));
+                     for (int i = 8; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(w));)
+            }
+        } else if constexpr (MODE == 13 || MODE == 14) {
+            // MFMA on fp16 SUBNORMAL A operands (the lo weight plane of the hi+lo split is mostly subnormal): same rate?
+            half8 fd;
+            for (int i = 0; i < 8; ++i) fd[i] = (_Float16)(MODE == 13 ? 3.0e-6f * (1 + (lane + i) % 7) : 0.f);
+            REP16(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fd, fb, acc, 0, 0, 0);)
+            REP16(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fd, fb, acc, 0, 0, 0);)
+            REP16(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fd, fb, acc, 0, 0, 0);)
+            REP16(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fd, fb, acc, 0, 0, 0);)
         } else if constexpr (MODE == 9) {
             REP4(for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));)
         } else if constexpr (MODE == 10) {
@@ -107,6 +130,10 @@ int main() {
     run<6>("v_mfma_f32_32x32x16_f16", 64, out, cyc);
     run<7>("waves 0-3 mfma x16 | waves 4+ v_fma x128", 16, out, cyc);
     run<8>("1 mfma + 6 v_fma interleaved (per group of 7)", 16, out, cyc);
+    run<11>("slot: P 16x(mfma+4fma) | C 4x(2mfma+16fma) /16", 16, out, cyc);
+    run<12>("slot, P on two accumulators /16", 16, out, cyc);
+    run<13>("mfma, A = fp16 subnormals", 64, out, cyc);
+    run<14>("mfma, A = zeros", 64, out, cyc);
     run<9>("v_exp_f32", 64, out, cyc);
     run<10>("ds_read_b128 (16 in flight)", 64, out, cyc);
     return 0;

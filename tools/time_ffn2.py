@@ -42,6 +42,22 @@ def gen2():
     assert L.ira_op_ffn2(be.handle, p(x), p(out), p(v), p(Md), stride, None, 1, Cc, p(d['b.pin_w']), None, p(d['b.dw2_u']), None, p(d['b.pout_w']), None, T, H, W, Hp) == 0
 def gen2_nofold():
     assert L.ira_op_ffn2(be.handle, p(x), p(out), None, None, 0, None, 1, Cc, p(d['b.pin_w']), None, p(d['b.dw2_u']), None, p(d['b.pout_w']), None, T, H, W, Hp) == 0
+if os.environ.get('IRA_FFN2_DBG'):
+    for _ in range(2): gen2_nofold()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): gen2_nofold()
+    torch.cuda.synchronize()
+    print('IRA_FFN2_DBG=%s T=%d C=%d no fold: %.3f ms' % (os.environ['IRA_FFN2_DBG'], T, Cc, (time.perf_counter() - t0) * 100))
+    if os.environ['IRA_FFN2_DBG'] in ('4', '9'):
+        buf = (C.c_ulonglong * 128)()
+        assert L.ira_debug_ffn2_stamps(buf) == 0
+        P_ = [buf[i] for i in range(64)]; C_ = [buf[64 + i] for i in range(64)]
+        t0 = min(P_[0], C_[0])
+        print('P wave 0 stamps:', [int(v_ - t0) for v_ in P_[:32] if v_])
+        print('C wave 4 stamps:', [int(v_ - t0) for v_ in C_[:32] if v_])
+        print('P slot stamps (interval 5: before wait, after wait, ...):', [int(v_ - t0) for v_ in P_[32:] if v_])
+        print('C slot stamps:', [int(v_ - t0) for v_ in C_[32:] if v_])
+    sys.exit(0)
 fns = [('gen1 apply+ffn_fused', gen1), ('gen1 ffn_fused only', gen1_ffn_only), ('gen2 ffn2 with fold', gen2), ('gen2 ffn2 no fold', gen2_nofold)]
 for _, f in fns: f()
 torch.cuda.synchronize()
