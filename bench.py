@@ -660,6 +660,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # Data path: RCCL issued by libira_hip.so on its own stream (ira_amd.dist.init_comm).  torch.distributed is the harness' control plane only
+    # (the barrier and the MAX of the step time the contract asks for): a gloo group on the CPU.
     # IRA_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box (all ranks on GPU 0, collectives staged by gloo); never a result
     backend = os.environ.get('IRA_DIST_BACKEND', 'nccl')
     if backend != 'nccl':
@@ -669,10 +671,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
 
     cfg = task_config('Real_Denoising')          # LayerNorm BiasFree, demo.py:59-61
     be = RestormerBackend(cfg, seeded_state_dict(cfg, 0), device=local_rank)
@@ -684,13 +683,25 @@ def main():
     out = torch.empty_like(frame)
     Hp, Wp, th, tw, n_rows, n_cols = _capi.tile_plan(h, w, args.tile, args.overlap)
     n_tiles = n_rows * n_cols
-    rst = TileParallelRestorer(be, rank, world)
     whole = args.workload == 'restormer4k_whole'
+    gather = None
+    if world > 1:
+        if backend == 'nccl':
+            from ira_amd.dist import init_comm
+            init_comm(be, rank, world)                # ncclCommInitRank inside the library; the id travels over a TCP socket
+        else:
+            from ira_amd.test_transports import GlooTileGather
+            gather = GlooTileGather(via_host=True)
+    rst = TileParallelRestorer(be, rank, world, gather=gather)
     if whole and world > 1:
-        # the untiled frame in `world` horizontal bands, halo rows and Gram records over RCCL (ira_amd/dist.py)
+        # the untiled frame in `world` horizontal bands; halo rows and Gram records by ncclSend / ncclRecv / ncclAllGather
+        # on the model's stream (ira_strip_restore_u8_device)
         from ira_amd.dist import StripParallelRestorer
-        from ira_amd.dist import TorchDistTransport
-        srst = StripParallelRestorer(be, rank, world, transport=TorchDistTransport(rank, world, via_host=backend != 'nccl'))
+        if backend == 'nccl':
+            srst = StripParallelRestorer(be, rank, world)
+        else:
+            from ira_amd.test_transports import TorchDistTransport
+            srst = StripParallelRestorer(be, rank, world, transport=TorchDistTransport(rank, world, via_host=True))
 
         class _Bands:
             def restore_frame(self, frame, tile, overlap, out=None):
@@ -714,7 +725,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

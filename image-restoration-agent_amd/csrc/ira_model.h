@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/ira.h"
 #include "ira_kernels.h"
+#include "ira_comm.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -123,6 +124,14 @@ struct ira_model {
     bool strip_set = false, strip_on = false;
     ira_strip_comm scomm{};
     int strip_top = 0, strip_bot = 0;     // halo rows at level 1 (0 or 8)
+    // RCCL communicator of this handle (ira_comm_init): the tile all-gather and, when strip_rccl is set, the band exchange steps run on
+    // the model's stream with no host synchronisation
+    ira_comm::Comm* comm = nullptr;
+    bool strip_rccl = false;
+    char* strip_buf = nullptr; size_t strip_buf_bytes = 0;      // library-owned staging of the band exchange (RCCL mode)
+    float* dist_tiles = nullptr; size_t dist_tiles_bytes = 0;   // all tiles of a frame (all-gather destination)
+    int* strip_desc = nullptr;                                  // device copy of the band descriptor of ira_strip_restore_u8_device
+    int strip_desc_host[6] = {0, 0, 0, 0, 0, 0};
     void *qkvp, *qk, *v, *hp, *g, *M;
     int max_batch = 0;
     // harness scratch

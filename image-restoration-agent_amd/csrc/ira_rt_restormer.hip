@@ -218,8 +218,14 @@ static int strip_halo(ira_model* m, float* x, int H, int W, int C, int lv) {
     if (nbytes > cm.edge_capacity) return m->fail(IRA_ERR_ARG, "strip halo row of %zu bytes exceeds edge_capacity %zu", nbytes, (size_t)cm.edge_capacity);
     if (top) HIP_TRY(m, hipMemcpyAsync(cm.send_top, x + (size_t)top * row, nbytes, hipMemcpyDeviceToDevice, m->st));
     if (bot) HIP_TRY(m, hipMemcpyAsync(cm.send_bot, x + (size_t)(H - bot - 1) * row, nbytes, hipMemcpyDeviceToDevice, m->st));
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    if (cm.exchange(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip halo exchange callback failed");
+    if (m->strip_rccl) {            // ncclSend / ncclRecv with both neighbours, enqueued on the model's stream: the host never waits
+        if (!ira_comm::exchange_neighbours(m->comm, top ? cm.rank - 1 : -1, cm.send_top, cm.recv_top, bot ? cm.rank + 1 : -1, cm.send_bot, cm.recv_bot,
+                                           nbytes, m->st))
+            return m->fail(IRA_ERR_COMM, "strip halo exchange: %s", ira_comm::last_error());
+    } else {
+        HIP_TRY(m, hipStreamSynchronize(m->st));
+        if (cm.exchange(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip halo exchange callback failed");
+    }
     if (top) HIP_TRY(m, hipMemcpyAsync(x + (size_t)(top - 1) * row, cm.recv_top, nbytes, hipMemcpyDeviceToDevice, m->st));
     if (bot) HIP_TRY(m, hipMemcpyAsync(x + (size_t)(H - bot) * row, cm.recv_bot, nbytes, hipMemcpyDeviceToDevice, m->st));
     return IRA_OK;
@@ -237,8 +243,13 @@ static int strip_gram_mix(ira_model* m, const Blk& b, int H, int W, int C, int h
     const _Float16* qk = (const _Float16*)m->qk + (size_t)top * bpr * 2 * C * 8;       // [nblk][2C][8]: rows are runs of bpr blocks
     RUN(m, kg, ira::launch_gram(m->st, qk, m->part, 1, (int)nblk, C, heads, S));
     RUN(m, kg, ira::launch_sum_records(m->st, m->part, S, reclen, (float*)cm.gather_send));
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    if (cm.allgather(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip Gram all-gather callback failed");
+    if (m->strip_rccl) {
+        if (!ira_comm::all_gather(m->comm, cm.gather_send, cm.gather_recv, nbytes, m->st))
+            return m->fail(IRA_ERR_COMM, "strip Gram all-gather: %s", ira_comm::last_error());
+    } else {
+        HIP_TRY(m, hipStreamSynchronize(m->st));
+        if (cm.allgather(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip Gram all-gather callback failed");
+    }
     RUN(m, km, ira::launch_attn_mix(m->st, (const float*)cm.gather_recv, b.wo, b.temp, m->attnA, m->M, 1, C, heads, cm.world, NBc));
     return IRA_OK;
 }

@@ -376,6 +376,10 @@ int ira_model_destroy(ira_model_t* m) {
     if (!m) return IRA_OK;
     hipSetDevice(m->device);
     if (m->st) hipStreamSynchronize(m->st);
+    if (m->comm) ira_comm::destroy(m->comm);
+    if (m->strip_buf) hipFree(m->strip_buf);
+    if (m->strip_desc) hipFree(m->strip_desc);
+    if (m->dist_tiles) hipFree(m->dist_tiles);
     if (m->ws) hipFree(m->ws);
     if (m->xr_up) hipFree(m->xr_up);
     if (m->hs) hipFree(m->hs);
@@ -413,19 +417,18 @@ int ira_forward_device(ira_model_t* m, const float* in, int B, int H, int W, flo
 
 int ira_strip_configure(ira_model_t* m, const ira_strip_comm* comm) {
     ENTER(m);
-    if (comm == nullptr) { m->strip_set = false; return IRA_OK; }
+    if (comm == nullptr) { m->strip_set = false; m->strip_rccl = false; return IRA_OK; }
     if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "ira_strip_configure: Restormer handles only");
     if (!comm->exchange || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
         return m->fail(IRA_ERR_ARG, "ira_strip_configure: callbacks must be set and 0 <= rank < world");
     if (!comm->gather_send || !comm->gather_recv || (comm->world > 1 && (!comm->send_top || !comm->recv_top || !comm->send_bot || !comm->recv_bot)))
         return m->fail(IRA_ERR_ARG, "ira_strip_configure: NULL staging buffer");
     m->scomm = *comm;
-    m->strip_set = true;
+    m->strip_set = true; m->strip_rccl = false;
     return IRA_OK;
 }
 
-int ira_strip_buffer_bytes(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_t* record_bytes) {
-    ENTER(m);
+static int strip_buffer_bytes_locked(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_t* record_bytes) {
     if (m->arch != 0 || m->xr || Wp <= 0 || !edge_bytes || !record_bytes) return m->fail(IRA_ERR_ARG, "ira_strip_buffer_bytes: Restormer handle, Wp > 0");
     const ira_restormer_config& c = m->cfg;
     uint64_t rec = 0, edge = 0;
@@ -438,6 +441,135 @@ int ira_strip_buffer_bytes(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_
     rec = std::max<uint64_t>(rec, (uint64_t)c.heads[0] * (ch1 * ch1 + 2 * ch1) * 4);
     edge = std::max<uint64_t>(edge, (uint64_t)Wp * C1 * 4);
     *edge_bytes = edge; *record_bytes = rec;
+    return IRA_OK;
+}
+
+int ira_strip_buffer_bytes(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_t* record_bytes) {
+    ENTER(m);
+    return strip_buffer_bytes_locked(m, Wp, edge_bytes, record_bytes);
+}
+
+// ---- RCCL behind the ABI (ira_comm.hip)
+int ira_comm_unique_id(void* id_out) {
+    if (!id_out) return gfail(IRA_ERR_ARG, "ira_comm_unique_id: NULL buffer");
+    if (!ira_comm::get_unique_id(id_out)) return gfail(IRA_ERR_COMM, "%s", ira_comm::last_error());
+    return IRA_OK;
+}
+
+int ira_comm_init(ira_model_t* m, const void* id, int rank, int world) {
+    ENTER(m);
+    if (!id) return m->fail(IRA_ERR_ARG, "ira_comm_init: NULL id");
+    if (m->comm) { ira_comm::destroy(m->comm); m->comm = nullptr; m->strip_rccl = false; }
+    m->comm = ira_comm::init_rank(id, rank, world);
+    if (!m->comm) return m->fail(IRA_ERR_COMM, "ira_comm_init: %s", ira_comm::last_error());
+    return IRA_OK;
+}
+
+int ira_comm_destroy(ira_model_t* m) {
+    ENTER(m);
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    if (m->comm) ira_comm::destroy(m->comm);
+    m->comm = nullptr; m->strip_rccl = false;
+    if (m->strip_set && !m->scomm.exchange) m->strip_set = false;
+    return IRA_OK;
+}
+
+int ira_comm_rank(ira_model_t* m, int* rank, int* world) {
+    ENTER(m);
+    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_comm_rank: no communicator (ira_comm_init)");
+    if (rank) *rank = ira_comm::rank(m->comm);
+    if (world) *world = ira_comm::world(m->comm);
+    return IRA_OK;
+}
+
+static int strip_use_comm_locked(ira_model_t* m, int Wp) {
+    if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "ira_strip_use_comm: Restormer handles only");
+    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_strip_use_comm: no communicator (ira_comm_init)");
+    uint64_t edge = 0, rec = 0;
+    int rc = strip_buffer_bytes_locked(m, Wp, &edge, &rec);
+    if (rc != IRA_OK) return rc;
+    const int world = ira_comm::world(m->comm);
+    const size_t e = al256(edge), r1 = al256(rec), need = 4 * e + r1 + al256(rec * world);
+    if (need > m->strip_buf_bytes) {
+        HIP_TRY(m, hipStreamSynchronize(m->st));
+        if (m->strip_buf) { HIP_TRY(m, hipFree(m->strip_buf)); m->strip_buf = nullptr; m->strip_buf_bytes = 0; }
+        hipError_t he = hipMalloc((void**)&m->strip_buf, need);
+        if (he != hipSuccess) { m->strip_buf = nullptr; return m->fail(IRA_ERR_OOM, "strip staging hipMalloc(%zu): %s", need, hipGetErrorString(he)); }
+        m->strip_buf_bytes = need;
+    }
+    ira_strip_comm cm{};
+    cm.rank = ira_comm::rank(m->comm); cm.world = world;
+    cm.send_top = m->strip_buf; cm.recv_top = m->strip_buf + e; cm.send_bot = m->strip_buf + 2 * e; cm.recv_bot = m->strip_buf + 3 * e;
+    cm.edge_capacity = edge;
+    cm.gather_send = m->strip_buf + 4 * e; cm.gather_recv = m->strip_buf + 4 * e + r1;
+    cm.gather_capacity = rec;
+    m->scomm = cm;
+    m->strip_set = true; m->strip_rccl = true;
+    return IRA_OK;
+}
+
+int ira_strip_use_comm(ira_model_t* m, int Wp) {
+    ENTER(m);
+    return strip_use_comm_locked(m, Wp);
+}
+
+// Rows [r0, r1) of band `rank`: the Hp / 8 row groups of the coarsest U-Net level dealt out as evenly as possible, in order.
+static void strip_rows(int Hp, int world, int rank, int* r0, int* r1, int* rows_max) {
+    const int units = Hp / 8, base = units / world, rem = units % world;
+    int r = 0;
+    for (int i = 0; i < world; ++i) {
+        const int n = 8 * (base + (i < rem ? 1 : 0));
+        if (i == rank) { *r0 = r; *r1 = r + n; }
+        r += n;
+    }
+    *rows_max = 8 * (base + (rem ? 1 : 0));
+}
+
+int ira_strip_restore_u8_device(ira_model_t* m, const uint8_t* frame, int h, int w, int c, uint8_t* out) {
+    ENTER(m);
+    if (!frame || !out) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: NULL buffer");
+    if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: Restormer handles only");
+    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: no communicator (ira_comm_init)");
+    if (c != m->cfg.inp_channels || h <= 0 || w <= 0) return m->fail(IRA_ERR_ARG, "image is %dx%dx%d, model wants %d channels", h, w, c, m->cfg.inp_channels);
+    const int Hp = (h % 8) ? ((h + 8) / 8) * 8 : h, Wp = (w % 8) ? ((w + 8) / 8) * 8 : w;      // demo.py:123-126: pad only where needed
+    const int rank = ira_comm::rank(m->comm), world = ira_comm::world(m->comm);
+    if (Hp / 8 < world) return m->fail(IRA_ERR_ARG, "a padded height of %d rows cannot be split into %d bands of whole 8-row groups", Hp, world);
+    int rc = strip_use_comm_locked(m, Wp);
+    if (rc != IRA_OK) return rc;
+    int r0 = 0, r1 = 0, rows_max = 0;
+    strip_rows(Hp, world, rank, &r0, &r1, &rows_max);
+    const int top = rank > 0 ? 8 : 0, bot = rank < world - 1 ? 8 : 0, band = r1 - r0 + top + bot;
+    const size_t fbytes = al256((size_t)band * Wp * c * sizeof(float)), slot = al256((size_t)rows_max * w * c), gather = slot * world;
+    if ((rc = ensure_scratch(m, 2 * fbytes + gather)) != IRA_OK) return rc;
+    float* in_band = (float*)m->hs;
+    float* out_band = (float*)(m->hs + fbytes);
+    uint8_t* gbuf = (uint8_t*)(m->hs + 2 * fbytes);
+    if (!m->strip_desc) HIP_TRY(m, hipMalloc((void**)&m->strip_desc, 6 * sizeof(int)));
+    // descriptor of the pad-crop kernels: haloed band (y0, x0), interior rows as the core (padded-frame coordinates)
+    const int d[6] = {r0 - top, 0, r0, 0, r1 - r0, Wp};
+    if (memcmp(d, m->strip_desc_host, sizeof d) != 0) {
+        HIP_TRY(m, hipStreamSynchronize(m->st));
+        memcpy(m->strip_desc_host, d, sizeof d);
+        HIP_TRY(m, hipMemcpy(m->strip_desc, d, sizeof d, hipMemcpyHostToDevice));
+    }
+    // /255 + reflect padding of this band (demo.py:120-127), band forward, clamp / round / crop of the interior rows into `out` (:155-161)
+    RUN(m, "strip_extract", ira::launch_extract_list(m->st, frame, h, w, c, band, Wp, m->strip_desc, 1, in_band));
+    if ((rc = restormer_strip_forward_enqueue(m, in_band, band, Wp, top, bot, out_band)) != IRA_OK) return rc;
+    RUN(m, "strip_to_u8", ira::launch_scatter_cores(m->st, out_band, band, Wp, c, m->strip_desc, 1, (r1 - r0) * Wp, h, w, out, 1));
+    if (world > 1) {
+        // every rank's rows to every rank: equal slots of rows_max rows (bands differ by at most 8 rows), all-gathered in place
+        const int my_rows = std::max(0, std::min(r1, h) - r0);
+        if (my_rows > 0) HIP_TRY(m, hipMemcpyAsync(gbuf + slot * rank, out + (size_t)r0 * w * c, (size_t)my_rows * w * c, hipMemcpyDeviceToDevice, m->st));
+        if (!ira_comm::all_gather(m->comm, gbuf + slot * rank, gbuf, slot, m->st)) return m->fail(IRA_ERR_COMM, "band all-gather: %s", ira_comm::last_error());
+        for (int i = 0; i < world; ++i) {
+            if (i == rank) continue;
+            int a = 0, b = 0, rm = 0;
+            strip_rows(Hp, world, i, &a, &b, &rm);
+            const int rows = std::max(0, std::min(b, h) - a);
+            if (rows > 0) HIP_TRY(m, hipMemcpyAsync(out + (size_t)a * w * c, gbuf + slot * i, (size_t)rows * w * c, hipMemcpyDeviceToDevice, m->st));
+        }
+    }
+    HIP_TRY(m, hipStreamSynchronize(m->st));
     return IRA_OK;
 }
 
@@ -509,6 +641,36 @@ int ira_restore_tiles_device(ira_model_t* m, const uint8_t* frame, int h, int w,
     if (n_tiles == 0) return IRA_OK;
     rc = restore_tiles_enqueue(m, frame, h, w, c, p, first_tile, n_tiles, tiles_out);
     if (rc != IRA_OK) return rc;
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
+int ira_restore_frame_distributed(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap, uint8_t* out) {
+    ENTER(m);
+    if (!frame || !out) return m->fail(IRA_ERR_ARG, "ira_restore_frame_distributed: NULL buffer");
+    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_restore_frame_distributed: no communicator (ira_comm_init)");
+    if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
+    Plan p; std::string err;
+    int rc = plan_for(m, h, w, tile, overlap, p, err);
+    if (rc != IRA_OK) return m->fail(rc, "%s", err.c_str());
+    // block partition of the row-major tile list in equal chunks of ceil(n / world): the gathered buffer is then in tile order
+    const int rank = ira_comm::rank(m->comm), world = ira_comm::world(m->comm);
+    const int nt = p.n_rows * p.n_cols, chunk = (nt + world - 1) / world;
+    const int first = std::min(rank * chunk, nt), count = std::max(0, std::min(chunk, nt - first));
+    const int s = model_scale(m);
+    const size_t tile_bytes = (size_t)p.th * s * p.tw * s * c * sizeof(float), need = tile_bytes * chunk * world;
+    if (need > m->dist_tiles_bytes) {
+        HIP_TRY(m, hipStreamSynchronize(m->st));
+        if (m->dist_tiles) { HIP_TRY(m, hipFree(m->dist_tiles)); m->dist_tiles = nullptr; m->dist_tiles_bytes = 0; }
+        hipError_t he = hipMalloc((void**)&m->dist_tiles, need);
+        if (he != hipSuccess) { m->dist_tiles = nullptr; return m->fail(IRA_ERR_OOM, "tile buffer hipMalloc(%zu): %s", need, hipGetErrorString(he)); }
+        m->dist_tiles_bytes = need;
+    }
+    char* mine = (char*)m->dist_tiles + tile_bytes * chunk * rank;
+    if (count > 0 && (rc = restore_tiles_enqueue(m, frame, h, w, c, p, first, count, (float*)mine)) != IRA_OK) return rc;
+    if (world > 1 && !ira_comm::all_gather(m->comm, mine, m->dist_tiles, tile_bytes * chunk, m->st))       // in place, on the model's stream
+        return m->fail(IRA_ERR_COMM, "tile all-gather: %s", ira_comm::last_error());
+    if ((rc = blend_enqueue(m, m->dist_tiles, h, w, c, p, out)) != IRA_OK) return rc;
     HIP_TRY(m, hipStreamSynchronize(m->st));
     return IRA_OK;
 }

@@ -96,6 +96,13 @@ SIGNATURES = {
     'ira_strip_configure': (_i, [_vp, C.POINTER(IraStripComm)]),
     'ira_strip_buffer_bytes': (_i, [_vp, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'ira_strip_forward_device': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'ira_comm_unique_id': (_i, [_vp]),
+    'ira_comm_init': (_i, [_vp, _vp, _i, _i]),
+    'ira_comm_destroy': (_i, [_vp]),
+    'ira_comm_rank': (_i, [_vp, _pi, _pi]),
+    'ira_restore_frame_distributed': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ira_strip_use_comm': (_i, [_vp, _i]),
+    'ira_strip_restore_u8_device': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ira_tile_plan': (_i, [_i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi]),
     'ira_model_tile_plan': (_i, [_vp, _i, _i, _i, _i, _pi, _pi, _pi, _pi, _pi, _pi, _pi]),
     'ira_restore_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -176,6 +183,14 @@ def device_count() -> int:
     if rc != 0:
         return 0
     return n.value
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0); 128 bytes to carry to the other ranks."""
+    lib = load_library()
+    buf = (C.c_char * 128)()
+    check(lib.ira_comm_unique_id(buf), None, 'ira_comm_unique_id')
+    return bytes(buf)
 
 
 def tile_plan(h: int, w: int, tile, overlap: int):

@@ -162,6 +162,35 @@ class _Backend:
     def set_fused_ffn(self, on: bool):
         self._ck(self._lib.ira_set_fused_ffn(self._h, 1 if on else 0), 'ira_set_fused_ffn')
 
+    # -- RCCL communicator of this handle (csrc/ira_comm.hip)
+    has_comm = False
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        if len(uid) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        self._ck(self._lib.ira_comm_init(self._h, buf, int(rank), int(world)), 'ira_comm_init')
+        self.has_comm = True
+
+    def comm_destroy(self):
+        if self.has_comm:
+            self._ck(self._lib.ira_comm_destroy(self._h), 'ira_comm_destroy')
+            self.has_comm = False
+
+    def restore_frame_distributed_t(self, frame, tile, overlap, out):
+        assert frame.is_cuda and out.is_cuda and frame.is_contiguous() and out.is_contiguous()
+        h, w, c = frame.shape
+        rc = self._lib.ira_restore_frame_distributed(self._h, frame.data_ptr(), h, w, c, int(tile) if tile else 0, int(overlap), out.data_ptr())
+        self._ck(rc, 'ira_restore_frame_distributed')
+
+    def strip_use_comm(self, Wp: int):
+        self._ck(self._lib.ira_strip_use_comm(self._h, int(Wp)), 'ira_strip_use_comm')
+
+    def strip_restore_u8_t(self, frame, out):
+        assert frame.is_cuda and out.is_cuda and frame.is_contiguous() and out.is_contiguous()
+        h, w, c = frame.shape
+        self._ck(self._lib.ira_strip_restore_u8_device(self._h, frame.data_ptr(), h, w, c, out.data_ptr()), 'ira_strip_restore_u8_device')
+
     def set_ffn_generation(self, gen: int):
         self._ck(self._lib.ira_set_ffn_generation(self._h, int(gen)), 'ira_set_ffn_generation')
 

@@ -1,24 +1,79 @@
-"""Tile-parallel restoration across the GPUs of one node: one process per GPU, RCCL over xGMI.
+"""Restoration of one frame across the GPUs of one node: one process per GPU, RCCL over xGMI, issued by libira_hip.so itself.
 
-The reference runs the tiler as a Python double loop of batch-1 forwards on one GPU
-(demo.py:143-153; agentic_api.py:2 pins one device).  Tiles are independent forwards (per-tile
-attention statistics, per-tile zero padding), so the row-major tile list is block-partitioned over
-ranks; each rank runs its tiles as ONE batched forward, then a single all-gather of the restored
-tiles (float32 NHWC; 40 x 3 x 512 x 512 x 4 B = 126 MB for a 4K frame) gives every rank the whole
-list, and the E/W overlap-average runs on each rank in the reference's row-major order (bit-stable).
+The reference runs the tiler as a Python double loop of batch-1 forwards on one GPU (demo.py:143-153; agentic_api.py:2 pins one device).
+Tiles are independent forwards (per-tile attention statistics, per-tile zero padding), so the row-major tile list is block-partitioned over
+ranks; each rank runs its tiles as ONE batched forward, a single ncclAllGather of the restored tiles (float32 NHWC; 40 x 3 x 512 x 512 x 4 B =
+126 MB for a 4K frame) gives every rank the whole list, and the E/W overlap-average runs on each rank in the reference's row-major order
+(bit-stable).  All of that is ``ira_restore_frame_distributed`` (include/ira.h); this module only creates the communicator - the 128-byte
+RCCL id travels from rank 0 to the other ranks over a plain TCP socket - and mirrors the call.
 
-torch.distributed is plumbing only: backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
+No torch.distributed here: the classes take an optional TEST transport (ira_amd/test_transports.py) that replaces the library's RCCL calls
+when there is no communicator (CPU tests with gloo, single-GPU emulations).
 """
 from __future__ import annotations
+
+import os
+import socket
+import struct
+import time
 
 import torch
 
 from . import _capi
 
 
+def exchange_unique_id(rank: int, world: int, make_id, addr: str | None = None, port: int | None = None, timeout: float = 120.0) -> bytes:
+    """Rank 0 calls ``make_id()`` (-> 128 bytes) and serves it to the world - 1 other ranks over TCP; they connect (retrying while rank 0
+    is not listening yet) and read it.  addr / port default to MASTER_ADDR / MASTER_PORT + 29 of the torchrun environment."""
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = port or int(os.environ.get('MASTER_PORT', '29500')) + 29
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(struct.pack('<I', len(uid)) + uid)
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                n = struct.unpack('<I', _recvn(s, 4))[0]
+                return _recvn(s, n)
+        except (ConnectionRefusedError, socket.timeout, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.1)
+
+
+def _recvn(s, n):
+    buf = b''
+    while len(buf) < n:
+        chunk = s.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError('peer closed while sending the communicator id')
+        buf += chunk
+    return buf
+
+
+def init_comm(backend, rank: int, world: int, addr: str | None = None, port: int | None = None):
+    """Attach an RCCL communicator of ``world`` ranks to ``backend`` (one model handle on this rank's GPU)."""
+    uid = exchange_unique_id(rank, world, _capi.comm_unique_id, addr, port)
+    backend.comm_init(uid, rank, world)
+    return backend
+
+
 def block_partition(n_tiles: int, world: int, rank: int):
     """Contiguous blocks of ceil(n/world) tiles; trailing ranks may be short or empty.
-    With equal chunks the all-gathered buffer holds the tiles in row-major order already."""
+    With equal chunks the all-gathered buffer holds the tiles in row-major order already.  (The same rule as
+    csrc/ira_runtime.hip::ira_restore_frame_distributed.)"""
     chunk = (n_tiles + world - 1) // world
     first = min(rank * chunk, n_tiles)
     count = max(0, min(chunk, n_tiles - first))
@@ -26,17 +81,19 @@ def block_partition(n_tiles: int, world: int, rank: int):
 
 
 class TileParallelRestorer:
-    """``backend`` needs restore_tiles_t(frame, h, w, c, tile, overlap, first, n, out) and
-    blend_tiles_t(tiles, h, w, c, tile, overlap, out) on torch tensors (RestormerBackend provides them
-    on device pointers; the CPU tests inject a fake)."""
+    """One frame, tile-parallel.  With a communicator on the backend (``init_comm``) this is one call of
+    ``ira_restore_frame_distributed``.  Without one: world 1 runs extract / forward / blend locally; world > 1 needs a test ``gather``
+    (ira_amd/test_transports.py::GlooTileGather) and a backend with restore_tiles_t / blend_tiles_t (the CPU tests inject a fake)."""
 
-    def __init__(self, backend, rank: int = 0, world: int = 1, group=None, plan_fn=None):
+    def __init__(self, backend, rank: int = 0, world: int = 1, plan_fn=None, gather=None):
         self.be = backend
-        self.rank, self.world, self.group = rank, world, group
+        self.rank, self.world, self.gather = rank, world, gather
         # the plan of the model's own harness (SwinIR: always-pad rule, outputs scaled by `upscale`); plan functions may
         # return 6 values (scale 1) or 7
         self.plan_fn = plan_fn or getattr(backend, 'plan', None) or _capi.tile_plan
         self._bufs = {}
+        if world > 1 and gather is None and not getattr(backend, 'has_comm', False):
+            raise _capi.IraError("world > 1 needs an RCCL communicator on the backend (ira_amd.dist.init_comm) or a test gather transport")
 
     def _buffers(self, key, n_local, n_all, th, tw, c, device):
         if key not in self._bufs:
@@ -52,24 +109,18 @@ class TileParallelRestorer:
         plan = tuple(self.plan_fn(h, w, tile, overlap))
         Hp, Wp, th, tw, n_rows, n_cols = plan[:6]
         s = plan[6] if len(plan) > 6 else 1
+        if out is None:
+            out = torch.empty((h * s, w * s, c), dtype=torch.uint8, device=frame_u8.device)
+        if self.gather is None and getattr(self.be, 'has_comm', False):
+            self.be.restore_frame_distributed_t(frame_u8, tile, overlap, out)        # partition, forward, ncclAllGather, blend: in the library
+            return out
         nt = n_rows * n_cols
         first, count, chunk = block_partition(nt, self.world, self.rank)
         local, allt = self._buffers((h, w, c, tile, overlap), chunk, chunk * self.world, th * s, tw * s, c, frame_u8.device)
         if count > 0:
             self.be.restore_tiles_t(frame_u8, h, w, c, tile, overlap, first, count, local)
         if self.world > 1:
-            import torch.distributed as dist
-            # restore_tiles_t is host-synchronous, so `local` is complete before RCCL reads it
-            if frame_u8.is_cuda and dist.get_backend(self.group) == 'gloo':      # rehearsal on a one-GPU box: stage through the host
-                host = torch.empty(allt.numel(), dtype=allt.dtype)
-                dist.all_gather_into_tensor(host, local[:chunk].reshape(-1).cpu(), group=self.group)
-                allt.view(-1).copy_(host)
-            else:
-                dist.all_gather_into_tensor(allt.view(-1), local[:chunk].reshape(-1), group=self.group)
-            if frame_u8.is_cuda:
-                torch.cuda.synchronize(frame_u8.device)     # RCCL stream -> visible to the library stream
-        if out is None:
-            out = torch.empty((h * s, w * s, c), dtype=torch.uint8, device=frame_u8.device)
+            self.gather(local[:chunk].reshape(-1), allt.view(-1))
         self.be.blend_tiles_t(allt, h, w, c, tile, overlap, out)
         return out
 
@@ -78,7 +129,8 @@ class TileParallelRestorer:
 # Whole-frame (untiled) Restormer over the GPUs of a node: horizontal bands + halo rows + Gram all-gather.
 
 def strip_bounds(Hp: int, world: int):
-    """Rows [r0, r1) per rank: the Hp / 8 row groups of the coarsest U-Net level dealt out as evenly as possible, in order."""
+    """Rows [r0, r1) per rank: the Hp / 8 row groups of the coarsest U-Net level dealt out as evenly as possible, in order.
+    (The same rule as csrc/ira_runtime.hip::strip_rows.)"""
     units = Hp // 8
     if Hp % 8 or units < world:
         raise ValueError(f"a padded height of {Hp} rows cannot be split into {world} bands of whole 8-row groups")
@@ -91,99 +143,22 @@ def strip_bounds(Hp: int, world: int):
     return out
 
 
-class TorchDistTransport:
-    """The two exchange steps over torch.distributed (backend "nccl" = RCCL over xGMI).  ``via_host``: stage through host memory, for the
-    gloo backend in tests."""
-
-    def __init__(self, rank: int, world: int, group=None, via_host: bool = False):
-        self.rank, self.world, self.group, self.via_host = rank, world, group, via_host
-
-    def _peer(self, r):
-        import torch.distributed as dist
-        return r if self.group is None else dist.get_global_rank(self.group, r)
-
-    def exchange(self, send_top, recv_top, send_bot, recv_bot):
-        import torch.distributed as dist
-        h = (lambda t: t.cpu()) if self.via_host else (lambda t: t)
-        ops, back = [], []
-        if self.rank > 0:
-            r = h(recv_top)
-            ops += [dist.P2POp(dist.isend, h(send_top), self._peer(self.rank - 1), self.group), dist.P2POp(dist.irecv, r, self._peer(self.rank - 1), self.group)]
-            back.append((recv_top, r))
-        if self.rank < self.world - 1:
-            r = h(recv_bot)
-            ops += [dist.P2POp(dist.isend, h(send_bot), self._peer(self.rank + 1), self.group), dist.P2POp(dist.irecv, r, self._peer(self.rank + 1), self.group)]
-            back.append((recv_bot, r))
-        for w in dist.batch_isend_irecv(ops) if ops else []:
-            w.wait()
-        if self.via_host:
-            for dst, src in back:
-                dst.copy_(src)
-
-    def allgather(self, send, recv):
-        import torch.distributed as dist
-        if self.via_host:
-            r = recv.cpu()
-            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
-            recv.copy_(r)
-        else:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-
-
-class LocalTransport:
-    """world == 1: nothing to exchange, the gather is a copy."""
-
-    def exchange(self, send_top, recv_top, send_bot, recv_bot):
-        pass
-
-    def allgather(self, send, recv):
-        recv.copy_(send)
-
-
-class ThreadTransport:
-    """Emulation for one GPU: every band is driven by its own host thread and model handle in ONE process, the exchange steps are
-    device copies between the threads' staging tensors.  ``shared = ThreadTransport.make_shared(world)`` is common to all ranks."""
-
-    @staticmethod
-    def make_shared(world: int):
-        import threading
-        return {'barrier': threading.Barrier(world), 'slots': [None] * world}
-
-    def __init__(self, shared, rank: int, world: int):
-        self.sh, self.rank, self.world = shared, rank, world
-
-    def _sync(self, t):
-        if t.is_cuda:
-            torch.cuda.synchronize(t.device)
-
-    def exchange(self, send_top, recv_top, send_bot, recv_bot):
-        self.sh['slots'][self.rank] = (send_top, send_bot)
-        self.sh['barrier'].wait()
-        if self.rank > 0:
-            recv_top.copy_(self.sh['slots'][self.rank - 1][1])
-        if self.rank < self.world - 1:
-            recv_bot.copy_(self.sh['slots'][self.rank + 1][0])
-        self._sync(recv_top)
-        self.sh['barrier'].wait()
-
-    def allgather(self, send, recv):
-        self.sh['slots'][self.rank] = send
-        self.sh['barrier'].wait()
-        n = send.numel()
-        for i in range(self.world):
-            recv[i * n:(i + 1) * n].copy_(self.sh['slots'][i])
-        self._sync(recv)
-        self.sh['barrier'].wait()
-
-
 class StripParallelRestorer:
     """Rank ``rank`` of ``world`` restores its band of the frame; ``restore_frame`` returns the whole restored frame on every rank.
-    backend: RestormerBackend (strip_* methods).  transport: exchange(send_top, recv_top, send_bot, recv_bot) and allgather(send, recv)
-    on torch tensors (default: TorchDistTransport over the default process group)."""
+    With a communicator on the backend (``init_comm``) and no transport this is one call of ``ira_strip_restore_u8_device``: band cut-out,
+    /255, reflect padding, the band forward with ncclSend / ncclRecv / ncclAllGather on the model's stream, uint8 conversion and the
+    gather of the bands all happen in the library.  ``transport`` (ira_amd/test_transports.py) selects the callback form of the C ABI
+    instead (ira_strip_configure): exchange(send_top, recv_top, send_bot, recv_bot) and allgather(send, recv) on torch tensors."""
 
     def __init__(self, backend, rank: int = 0, world: int = 1, transport=None):
         self.be, self.rank, self.world = backend, rank, world
-        self.tr = transport or (LocalTransport() if world == 1 else TorchDistTransport(rank, world))
+        self.use_comm = transport is None and getattr(backend, 'has_comm', False)
+        if transport is None and not self.use_comm:
+            if world > 1:
+                raise _capi.IraError("world > 1 needs an RCCL communicator on the backend (ira_amd.dist.init_comm) or a test transport")
+            from .test_transports import LocalTransport
+            transport = LocalTransport()
+        self.tr = transport
         self._comm = None
         self._bufs = None
         self.error = None
@@ -220,6 +195,10 @@ class StripParallelRestorer:
         whole-image mode (:129-131): pad to a multiple of 8 by reflection only where needed, forward, clamp, crop, img_as_ubyte."""
         import torch.nn.functional as F
         h, w, c = frame_u8.shape
+        if self.use_comm and not return_float:
+            out = torch.empty_like(frame_u8)
+            self.be.strip_restore_u8_t(frame_u8, out)
+            return out
         x = frame_u8.permute(2, 0, 1).unsqueeze(0).float().div(255.)
         H, W = ((h + 8) // 8) * 8, ((w + 8) // 8) * 8                                        # demo.py:123-126
         padh, padw = (H - h if h % 8 else 0), (W - w if w % 8 else 0)

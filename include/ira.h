@@ -38,7 +38,7 @@ extern "C" {
 #define IRA_ERR_HIP        3
 #define IRA_ERR_WEIGHTS    4
 #define IRA_ERR_OOM        5
-#define IRA_ERR_COMM       6   /* a strip-parallel exchange callback returned non-zero */
+#define IRA_ERR_COMM       6   /* a strip-parallel exchange callback returned non-zero, or an RCCL call failed (ira_comm_*) */
 
 typedef struct ira_model ira_model_t;
 
@@ -262,6 +262,35 @@ int ira_restore_tiles_device(ira_model_t* model, const uint8_t* frame_u8_dev, in
  * rint(x*255) -> uint8 (demo.py:155-161).  tiles_dev holds ALL n_rows*n_cols tiles. */
 int ira_blend_tiles_device(ira_model_t* model, const float* tiles_dev, int h, int w, int c,
                            int tile, int overlap, uint8_t* out_u8_dev);
+
+/* ------------------------------------------------------------------ RCCL behind the ABI
+ * One process per GPU; the library owns the communicator and issues every collective on the model's own stream (csrc/ira_comm.hip; librccl.so is
+ * dlopen-ed by the first of these calls, a single-GPU process never loads it).  The caller only carries the 128-byte id from rank 0 to the
+ * other ranks (any side channel: a socket, a file, MPI, torch.distributed's store ...).
+ * Reference being replaced: the sequential Python tile loop of demo.py:143-153 (one GPU; AgentApp/agentic_api.py:2 pins it). */
+#define IRA_COMM_ID_BYTES 128
+int ira_comm_unique_id(void* id_out);                                            /* rank 0: ncclGetUniqueId */
+int ira_comm_init(ira_model_t* model, const void* id, int rank, int world);      /* ncclCommInitRank on the model's device */
+int ira_comm_destroy(ira_model_t* model);
+int ira_comm_rank(ira_model_t* model, int* rank, int* world);
+
+/* One frame, tile-parallel over the communicator's ranks: every rank holds the uint8 (h,w,c) frame in device memory, runs the block
+ * [rank*ceil(n/world), ...) of the row-major tile list as one batched forward, ONE ncclAllGather of the float32 tiles (in place, on the model's
+ * stream) gives every rank all tiles, and the E/W overlap average runs on every rank in the reference's row-major order (bit-stable): out_dev
+ * holds the same uint8 (h*s, w*s, c) frame on every rank.  world == 1 equals ira_restore_tiles_device + ira_blend_tiles_device. */
+int ira_restore_frame_distributed(ira_model_t* model, const uint8_t* frame_u8_dev, int h, int w, int c, int tile, int overlap,
+                                  uint8_t* out_u8_dev);
+
+/* Band-parallel whole frame (ira_strip_forward_device) with the two exchange steps as ncclSend/ncclRecv and ncclAllGather on the model's
+ * stream instead of host callbacks: the library allocates the staging buffers for a padded frame width Wp; rank / world come from the
+ * communicator.  Replaces a previous ira_strip_configure. */
+int ira_strip_use_comm(ira_model_t* model, int Wp);
+
+/* The whole-frame harness of demo.py:120-131,155-161 (no tiler: model_services.yaml:74) over the communicator's ranks, all on the device and on
+ * the model's stream: this rank's band (rows of whole 8-row groups dealt out evenly, + 8 halo rows per neighbour) is cut out of the uint8 frame
+ * with the /255 and the pad-if-needed reflect padding, runs through ira_strip_forward_device's schedule with the RCCL exchange steps, its
+ * interior rows are clamped / rounded to uint8, and ONE ncclAllGather hands every rank every band: out_u8_dev (h,w,c) is the same on all ranks. */
+int ira_strip_restore_u8_device(ira_model_t* model, const uint8_t* frame_u8_dev, int h, int w, int c, uint8_t* out_u8_dev);
 
 /* ------------------------------------------------------------------ measurement */
 

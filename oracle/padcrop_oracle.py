@@ -1,9 +1,13 @@
 """CPU ORACLE for the pad-crop tiler -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 Restates X-Restormer/xrestormer/models/xrestormer_model.py: pre_process :53-63, tile_process :65-133, post_process
-:134-136, for scale 1, around any ``forward_fn`` (NCHW float tensor -> same).  The uint8 conversion around it
-(SingleImageDataset / tensor2img) lives in pip basicsr, which is not in /root/reference: at that boundary parity is UNPINNED
-(SURVEY 8c); it is restated as /255 in, clamp(0,1) -> round-half-even(x*255) out, like the Restormer harness."""
+:134-136, around any ``forward_fn`` (NCHW float tensor -> same, times ``scale``), and the same tiler as DiffBIR's RealESRGANer runs it
+(utils/realesrgan/realesrganer.py:71-183: pre_pad, mod-pad by scale, tile_process, un-pad).
+PINNED (round 2): tests/golden/make_golden_padcrop.py executes the reference's own methods (unbound, on a namespace carrying the attributes
+they read, with the reference networks) and stores their float outputs; tests/test_padcrop.py checks both functions below against them.
+The uint8 conversion around the tensor path (SingleImageDataset / tensor2img / cv2) lives in pip basicsr / OpenCV, which are not in
+/root/reference: that boundary alone stays unpinned; it is restated as /255 in, clamp(0,1) -> round-half-even(x*255) out, like the
+Restormer harness."""
 from __future__ import annotations
 
 import math
@@ -36,6 +40,27 @@ def padcrop_restore(lq, forward_fn, tile_size=None, tile_pad=32, padding_size=64
                 out[:, :, sy * scale:ey * scale, sx * scale:ex * scale] = tile[:, :, oy:oy + (ey - sy) * scale, ox:ox + (ex - sx) * scale]   # :117-133
     _, _, H, W = out.shape
     return out[:, :, 0:H - mod_pad_h * scale, 0:W - mod_pad_w * scale]                   # :134-136
+
+
+def realesrganer_restore(img, forward_fn, scale, tile_size=0, tile_pad=10, pre_pad=0):
+    """RealESRGANer.pre_process / process / tile_process / post_process (realesrganer.py:71-183).  img: (1,C,h,w) float tensor."""
+    if pre_pad:
+        img = F.pad(img, (0, pre_pad, 0, pre_pad), 'reflect')                            # :80-81
+    mod_scale = 2 if scale == 2 else (4 if scale == 1 else None)                         # :83-86
+    mph = mpw = 0
+    if mod_scale is not None:
+        _, _, h, w = img.shape
+        mph = (mod_scale - h % mod_scale) if h % mod_scale else 0                        # :89-92
+        mpw = (mod_scale - w % mod_scale) if w % mod_scale else 0
+        img = F.pad(img, (0, mpw, 0, mph), 'reflect')                                    # :93
+    # the tile loop (:99-165) is the loop of xrestormer_model.py:65-133 with no further padding
+    out = padcrop_restore(img, forward_fn, tile_size if tile_size > 0 else None, tile_pad, 1, scale)
+    _, _, H, W = out.shape
+    out = out[:, :, 0:H - mph * scale, 0:W - mpw * scale]                                # :169-171
+    if pre_pad:
+        _, _, H, W = out.shape
+        out = out[:, :, 0:H - pre_pad * scale, 0:W - pre_pad * scale]                    # :173-175
+    return out
 
 
 def padcrop_restore_image(img_u8, forward_fn, tile_size=None, tile_pad=32, padding_size=64, scale=1):

@@ -103,9 +103,11 @@ def _free_port():
 
 
 def _make(kind, rank, world):
+    from ira_amd.test_transports import GlooTileGather
+    gather = GlooTileGather() if world > 1 else None          # the product path all-gathers inside libira_hip.so (RCCL); this is the CPU stand-in
     if kind == 'sr':
-        return TileParallelRestorer(CpuSrBackend(), rank, world, plan_fn=sw_plan)
-    return TileParallelRestorer(CpuTileBackend(), rank, world, plan_fn=py_plan)
+        return TileParallelRestorer(CpuSrBackend(), rank, world, plan_fn=sw_plan, gather=gather)
+    return TileParallelRestorer(CpuTileBackend(), rank, world, plan_fn=py_plan, gather=gather)
 
 
 def _worker(rank, world, port, h, w, tile, overlap, q, kind='rst'):
@@ -142,6 +144,35 @@ def test_tile_parallel_matches_single_process(world, h, w, tile, overlap, kind):
         assert p.exitcode == 0
     for r in range(world):
         assert np.array_equal(results[r], single), r
+
+
+def test_world_gt_1_needs_a_communicator():
+    from ira_amd._capi import IraError
+    with pytest.raises(IraError, match='communicator'):
+        TileParallelRestorer(CpuTileBackend(), 0, 2, plan_fn=py_plan)
+    from ira_amd.dist import StripParallelRestorer
+    with pytest.raises(IraError, match='communicator'):
+        StripParallelRestorer(CpuStripBackend(), 0, 2)
+
+
+def _uid_worker(rank, world, port, q):
+    from ira_amd.dist import exchange_unique_id
+    q.put((rank, exchange_unique_id(rank, world, lambda: bytes(range(128)), '127.0.0.1', port)))
+
+
+def test_unique_id_travels_over_tcp():
+    """The only thing the host does for the RCCL communicator: carry rank 0's 128-byte id to the other ranks (ira_amd.dist)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, 3, port, q)) for r in (2, 1, 0)]      # rank 0 last: the others retry until it listens
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(3))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert all(got[r] == bytes(range(128)) for r in range(3))
 
 
 def test_block_partition_covers_in_order():
@@ -203,7 +234,8 @@ class CpuStripBackend:
 
 def _strip_worker(rank, world, port, h, w, q):
     import torch.distributed as dist
-    from ira_amd.dist import StripParallelRestorer, TorchDistTransport
+    from ira_amd.dist import StripParallelRestorer
+    from ira_amd.test_transports import TorchDistTransport
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)

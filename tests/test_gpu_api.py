@@ -69,6 +69,33 @@ def test_tile_parallel_restorer_world1(cache):
     assert np.array_equal(out, be.restore(noisy, tile=64, tile_overlap=32))
 
 
+def test_rccl_paths_with_one_rank():
+    """The collective entry points of the C ABI on a real communicator (csrc/ira_comm.hip: librccl.so dlopen-ed, ncclCommInitRank with one
+    rank, collectives enqueued on the model's stream): the tile-parallel frame and the band-parallel whole frame equal the single-GPU
+    entry points bit for bit.  (More than one rank needs more than one GPU: the driver's scaling runs.)"""
+    from ira_amd.backend import RestormerBackend
+    from ira_amd.config import reduced_config
+    from ira_amd.dist import StripParallelRestorer, TileParallelRestorer, init_comm
+    from ira_amd.weights import seeded_state_dict
+    cfg = reduced_config('BiasFree')
+    clean, noisy = O.synthetic_noisy_image(100, 131, 3, seed=21)
+    with RestormerBackend(cfg, seeded_state_dict(cfg, 1), device=0) as be:
+        ref_tiled = be.restore(noisy, tile=48, tile_overlap=16)
+        ref_whole = be.restore(noisy, tile=None)
+        init_comm(be, 0, 1)
+        assert be.has_comm
+        frame = torch.from_numpy(noisy).cuda()
+        out = TileParallelRestorer(be, 0, 1).restore_frame(frame, 48, 16).cpu().numpy()
+        assert np.array_equal(out, ref_tiled)
+        band = StripParallelRestorer(be, 0, 1).restore_frame(frame).cpu().numpy()
+        assert band.shape == ref_whole.shape and band.dtype == np.uint8
+        # one band = the whole frame; the band schedule sums its Gram records in another order than the one-launch path
+        d = np.abs(band.astype(int) - ref_whole.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+        be.comm_destroy()
+        assert not be.has_comm
+
+
 def test_fused_and_unfused_ffn_agree(cache):
     be = cache.get('Real_Denoising')
     g = torch.Generator().manual_seed(3)

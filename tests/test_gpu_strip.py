@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from ira_amd.config import reduced_config
-from ira_amd.dist import StripParallelRestorer, ThreadTransport
+from ira_amd.dist import StripParallelRestorer
+from ira_amd.test_transports import ThreadTransport
 from ira_amd.weights import seeded_state_dict, to_torch
 from oracle import restormer_oracle as O
 
@@ -96,7 +97,8 @@ def test_strip_forward_argument_checks():
     x = torch.zeros((24, 16, 3), device='cuda')
     with pytest.raises(IraError, match='ira_strip_configure first'):
         be.strip_forward_device(x.data_ptr(), 24, 16, 0, 0, x.data_ptr())
-    rst = StripParallelRestorer(be, 0, 1)
+    from ira_amd.test_transports import LocalTransport
+    rst = StripParallelRestorer(be, 0, 1, transport=LocalTransport())
     rst._configure(16, x.device)
     with pytest.raises(IraError, match='upper neighbour'):
         be.strip_forward_device(x.data_ptr(), 24, 16, 8, 0, x.data_ptr())      # rank 0 of 1 has no neighbours
