@@ -982,3 +982,61 @@ int ira_op_naf_sca(ira_model_t* m, const float* part, int blocks_per_image, long
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ brightening tools (no model handle: there are no weights)
+namespace {
+struct BrightenScratch { std::mutex mu; hipStream_t st = nullptr; uint8_t* io = nullptr; size_t io_bytes = 0; uint32_t* hist = nullptr; uint8_t* luts = nullptr; };
+BrightenScratch g_brighten[16];
+
+int brighten_check(int device, int tool, int h, int w, const void* a, const void* b) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gfail(IRA_ERR_NO_DEVICE, "no HIP device visible: libira_hip has no CPU fallback");
+    if (device < 0 || device >= ndev || device >= 16) return gfail(IRA_ERR_ARG, "device %d out of range (0..%d)", device, std::min(ndev, 16) - 1);
+    if (tool < 0 || tool > 2) return gfail(IRA_ERR_ARG, "ira_brighten: tool %d is not one of IRA_BRIGHTEN_*", tool);
+    if (!a || !b || h <= 0 || w <= 0) return gfail(IRA_ERR_ARG, "ira_brighten: bad image arguments (%p, %p, %d x %d)", a, b, h, w);
+    if (tool == 2 && (h < 16 || w < 16)) return gfail(IRA_ERR_ARG, "ira_brighten: CLAHE with 8 x 8 tiles needs a frame of at least 16 x 16, got %d x %d", h, w);
+    return IRA_OK;
+}
+#define G_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return gfail(e_ == hipErrorOutOfMemory ? IRA_ERR_OOM : IRA_ERR_HIP, \
+                                                                                    "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+int brighten_scratch(BrightenScratch& s, size_t io_bytes) {
+    if (!s.st) G_TRY(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    if (!s.hist) { G_TRY(hipMalloc((void**)&s.hist, 64 * 256 * 4)); G_TRY(hipMalloc((void**)&s.luts, 64 * 256)); }
+    if (io_bytes > s.io_bytes) {
+        if (s.io) { G_TRY(hipFree(s.io)); s.io = nullptr; s.io_bytes = 0; }
+        G_TRY(hipMalloc((void**)&s.io, io_bytes));
+        s.io_bytes = io_bytes;
+    }
+    return IRA_OK;
+}
+}  // namespace
+
+int ira_brighten_u8_device(int device, void* hip_stream, int tool, const uint8_t* in_rgb_dev, int h, int w, uint8_t* out_rgb_dev) {
+    int rc = brighten_check(device, tool, h, w, in_rgb_dev, out_rgb_dev);
+    if (rc != IRA_OK) return rc;
+    if (((uintptr_t)in_rgb_dev | (uintptr_t)out_rgb_dev) & 3) return gfail(IRA_ERR_ARG, "ira_brighten_u8_device: frames must be 4-byte aligned");
+    BrightenScratch& s = g_brighten[device];
+    std::lock_guard<std::mutex> lock(s.mu);
+    G_TRY(hipSetDevice(device));
+    rc = brighten_scratch(s, 0);
+    if (rc != IRA_OK) return rc;
+    G_TRY(ira::launch_brighten((hipStream_t)hip_stream, tool, in_rgb_dev, out_rgb_dev, h, w, s.hist, s.luts));
+    if (tool == 2) G_TRY(hipStreamSynchronize((hipStream_t)hip_stream));     // the CLAHE scratch is shared per device: held until the launch has drained
+    return IRA_OK;
+}
+
+int ira_brighten_u8(int device, int tool, const uint8_t* in_rgb_host, int h, int w, uint8_t* out_rgb_host) {
+    int rc = brighten_check(device, tool, h, w, in_rgb_host, out_rgb_host);
+    if (rc != IRA_OK) return rc;
+    BrightenScratch& s = g_brighten[device];
+    std::lock_guard<std::mutex> lock(s.mu);
+    G_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)h * w * 3, slot = al256(bytes + 16);
+    rc = brighten_scratch(s, 2 * slot);
+    if (rc != IRA_OK) return rc;
+    G_TRY(hipMemcpyAsync(s.io, in_rgb_host, bytes, hipMemcpyHostToDevice, s.st));
+    G_TRY(ira::launch_brighten(s.st, tool, s.io, s.io + slot, h, w, s.hist, s.luts));
+    G_TRY(hipMemcpyAsync(out_rgb_host, s.io + slot, bytes, hipMemcpyDeviceToHost, s.st));
+    G_TRY(hipStreamSynchronize(s.st));
+    return IRA_OK;
+}

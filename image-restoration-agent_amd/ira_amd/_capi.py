@@ -109,6 +109,8 @@ SIGNATURES = {
     'ira_restore_padcrop_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ira_restore_tiles_device': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ira_blend_tiles_device': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ira_brighten_u8': (_i, [_i, _i, _vp, _i, _i, _vp]),
+    'ira_brighten_u8_device': (_i, [_i, _vp, _i, _vp, _i, _i, _vp]),
     'ira_set_max_batch': (_i, [_vp, _i]),
     'ira_timer_start': (_i, [_vp]),
     'ira_timer_stop': (_i, [_vp, C.POINTER(C.c_float)]),
@@ -200,3 +202,22 @@ def tile_plan(h: int, w: int, tile, overlap: int):
     rc = lib.ira_tile_plan(h, w, int(tile) if tile else 0, int(overlap), *[C.byref(x) for x in v])
     check(rc, None, 'ira_tile_plan')
     return tuple(x.value for x in v)
+
+
+BRIGHTEN_TOOLS = {'constant_shift': 0, 'gamma_correction': 1, 'histogram_equalization': 2}     # IRA_BRIGHTEN_* of include/ira.h
+
+
+def brighten_u8(img, tool_name: str, device: int = 0):
+    """ira_brighten_u8 on a uint8 (h,w,3) RGB numpy image: what BrighteningTool._invoke does between imread and imwrite
+    (AgenticIR/executor/brightening/__init__.py:21-29).  Raises IraError without a gfx950 device: there is no CPU path."""
+    import numpy as np
+    lib = load_library()
+    if tool_name not in BRIGHTEN_TOOLS:
+        raise KeyError(f"brightening tools are {sorted(BRIGHTEN_TOOLS)}, not {tool_name!r}")
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("brighten_u8 expects a uint8 (h,w,3) RGB image")
+    out = np.empty_like(a)
+    rc = lib.ira_brighten_u8(int(device), BRIGHTEN_TOOLS[tool_name], a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data)
+    check(rc, None, 'ira_brighten_u8')
+    return out

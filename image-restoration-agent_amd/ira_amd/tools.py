@@ -550,6 +550,53 @@ class MPRNet(Tool):
             write_png(Path(self.output_dir) / (src.stem + '.png'), out)                                             # demo.py:86-87
 
 
+# ------------------------------------------------------------------------------------------------
+# brightening tools (AgenticIR/executor/brightening/__init__.py): HSV look-up on V, no weights
+class BrighteningTool(Tool):
+    """brightening/__init__.py:12-34: read the one input, RGB -> HSV, update V, HSV -> RGB, write ``output.png``.  The three cv2 calls
+    between imread and imwrite are one ira_brighten_u8 call (HIP kernels; no CPU path)."""
+
+    def __init__(self, tool_name: str, device: int = 0):
+        super().__init__(tool_name=tool_name, subtask="brightening")
+        self.device = device
+
+    def _invoke(self) -> None:
+        from ._capi import brighten_u8
+        input_path = list(self.input_dir.glob('*'))[0]
+        img = read_image(input_path)
+        write_png(self.output_dir / 'output.png', brighten_u8(img, self.tool_name, self.device))
+
+
+class ConstantShift(BrighteningTool):
+    """:37-44, V + 40 clipped to 255."""
+
+    def __init__(self, device: int = 0):
+        super().__init__(tool_name="constant_shift", device=device)
+
+
+class GammaCorrection(BrighteningTool):
+    """:47-54, 255 (V / 255) ** (1 / 1.5)."""
+
+    def __init__(self, device: int = 0):
+        super().__init__(tool_name="gamma_correction", device=device)
+
+
+class HistogramEqualization(BrighteningTool):
+    """:57-64, cv2.createCLAHE(clipLimit=2.0, tileGridSize=(8, 8)).apply(V)."""
+
+    def __init__(self, device: int = 0):
+        super().__init__(tool_name="histogram_equalization", device=device)
+
+
+def _default_device() -> int:
+    return int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+
+
+def brightening_toolbox(device: int = 0) -> list:
+    """brightening/__init__.py:68-73, the reference's order (MAXIM is commented out there)."""
+    return [HistogramEqualization(device), GammaCorrection(device), ConstantShift(device)]
+
+
 # subtask keys exactly as the reference registers them (executor/__init__.py:162-169)
 RESTORMER_SUBTASKS = {
     'denoising': 'denoising',
@@ -564,7 +611,7 @@ def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[
     """The tools this backend provides, under the reference's subtask keys and in the reference's toolbox order with the tools this
     backend does not build (MAXIM, DiffBIR, HAT, FBCNN, DRBNet, RIDCP, DehazeFormer) left out: denoising/__init__.py:12-19,
     motion_deblurring/__init__.py:10-15, defocus_deblurring/__init__.py:128-131, deraining/__init__.py:10-15, dehazing/__init__.py:51-56,
-    super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39."""
+    super_resolution/__init__.py:50-56, jpeg_compression_artifact_removal/__init__.py:34-39, brightening/__init__.py:68-73 (complete)."""
     R = lambda sub: Restormer(subtask=sub, cache=cache)
     X = lambda sub: XRestormer(sub, xrestormer_cache)
     M = lambda sub: MPRNet(sub, mprnet_cache)
@@ -577,12 +624,13 @@ def build_executor(cache: Optional[BackendCache] = None, swinir_cache: Optional[
     ex.register_subtask('deraining', [X('deraining'), R('deraining'), M('deraining')])
     ex.register_subtask('dehazing', [X('dehazing')])
     ex.register_subtask('jpeg compression artifact removal', [S('jpeg_compression_artifact_removal', '40')])
+    ex.register_subtask('brightening', brightening_toolbox(cache.device if cache is not None else _default_device()))
     return ex
 
 
 def install_into(reference_executor, cache: Optional[BackendCache] = None, swinir_cache: Optional[SwinIRCache] = None,
                  xrestormer_cache: Optional[XRestormerCache] = None, mprnet_cache: Optional[MPRNetCache] = None) -> int:
-    """Drop-in: replace every tool named 'restormer', 'swinir_*', 'xrestormer' or 'mprnet' in an existing
+    """Drop-in: replace every tool named 'restormer', 'swinir_*', 'xrestormer', 'mprnet' or one of the three brightening tools in an existing
     (reference) executor's toolboxes by the HIP-backed tool, leaving all other tools and the LLM orchestration untouched.
     Returns the count."""
     n = 0
@@ -601,6 +649,10 @@ def install_into(reference_executor, cache: Optional[BackendCache] = None, swini
                 n += 1
             elif name.startswith('swinir_') and sub in SWINIR_OPTS and name[7:] in SWINIR_OPTS[sub][1]:
                 toolbox[i] = SwinIR(subtask=sub, pretrained_on=name[7:], cache=swinir_cache)
+                n += 1
+            elif sub == 'brightening' and name in ('constant_shift', 'gamma_correction', 'histogram_equalization'):
+                toolbox[i] = {'constant_shift': ConstantShift, 'gamma_correction': GammaCorrection,
+                              'histogram_equalization': HistogramEqualization}[name](cache.device if cache is not None else _default_device())
                 n += 1
     return n
 

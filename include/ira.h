@@ -294,6 +294,18 @@ int ira_strip_restore_u8_device(ira_model_t* model, const uint8_t* frame_u8_dev,
 
 /* ------------------------------------------------------------------ measurement */
 
+/* ------------------------------------------------------------------ brightening tools (no weights, no handle)
+ * replaces BrighteningTool._invoke between cv2.imread and cv2.imwrite (AgenticIR/executor/brightening/__init__.py:19-31):
+ * cv2.cvtColor(BGR2HSV) -> _update_v(V) -> cv2.cvtColor(HSV2BGR), 8-bit, on RGB-ordered pixels (H, S, V do not depend on the channel order).
+ * tool: ConstantShift (:34-41, V + 40 clipped), GammaCorrection (:44-51, gamma 1.5), HistogramEqualization (:54-63, CLAHE clip 2.0, 8 x 8 tiles;
+ * frames of at least 16 x 16).  Errors go to ira_last_error(NULL). */
+#define IRA_BRIGHTEN_CONSTANT_SHIFT          0
+#define IRA_BRIGHTEN_GAMMA_CORRECTION        1
+#define IRA_BRIGHTEN_HISTOGRAM_EQUALIZATION  2
+int ira_brighten_u8(int device, int tool, const uint8_t* in_rgb_host, int h, int w, uint8_t* out_rgb_host);
+/* The same on frames already in HBM (4-byte aligned), enqueued on `hip_stream` (a hipStream_t, NULL = the default stream); in and out may not overlap. */
+int ira_brighten_u8_device(int device, void* hip_stream, int tool, const uint8_t* in_rgb_dev, int h, int w, uint8_t* out_rgb_dev);
+
 /* Upper bound on tiles per network launch (workspace is sized for it lazily). 0 = default. */
 int ira_set_max_batch(ira_model_t* model, int max_tiles);
 
