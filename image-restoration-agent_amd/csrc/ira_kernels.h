@@ -56,6 +56,11 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln
 
 // Fused attention apply + GDFN, second generation (ira_ffn2.hip): x_out = x1 + ffn(LN(x1)), x1 = x + M_t . v (+ wo_b); v == M == nullptr: x1 = x.
 // M: the per-tile matrices of launch_attn_mix (fp16 hi + lo planes, fragment-major), m_tile_stride in halfs.
+// ira_pw_wide.hip: LayerNorm + 1x1 for K = 192 with 512-pixel workgroups (arguments of launch_pw_kres)
+bool pw_wide_supported(int K, long npx);
+hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W, const float* bias, void* y, int y_stride,
+                          int n_store, int NB, int T, int P, float eps, int ln_n, int act);
+
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);
 

@@ -1501,6 +1501,7 @@ hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mod
                           const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     if (ln_n <= 0 || ln_n > K) ln_n = K;          // 0 = "all K channels are real"
     if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
+    if (pw_wide_supported(K, (long)T * P)) return launch_pw_wide(st, x, in_f32, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act);
     const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
     switch (K / 16) {
 #define IRA_CASE(KS_) case KS_: return pw_kres_dispatch<KS_>(st, x, in_f32, ln_mode, Wh, bias, yh, y_stride, n_store, NB, T, P, eps, ln_n, act);

@@ -82,6 +82,10 @@ def ln_core(x, mode):
     (192, 576, 2, True, 2, 31, True),
     (128, 64, 0, False, 2, 50, False),     # fp16 input, no LN
     (32, 96, 0, True, 1, 5, True),
+    (192, 1024, 1, True, 2, 16401, False),  # k_pw_wide (>= 32 768 px at K = 192): ragged last group of each tile, 16 iterations of 2 row blocks
+    (192, 520, 2, True, 3, 11000, True),    # k_pw_wide: 17 row blocks (odd: the last iteration has one), n_store not a multiple of 32, bias
+    (192, 576, 0, False, 1, 33000, False),  # k_pw_wide: fp16 input, partial last workgroup
+    (384, 1152, 1, True, 2, 8200, True),    # k_pw_wide at K = 384 (>= 16 384 px): one row block per iteration, 36 blocks
 ])
 def test_pw_kres(ctx, K, N, ln, in_f32, T, P, with_bias):
     g = torch.Generator().manual_seed(K * 7 + N)
