@@ -8,7 +8,10 @@
 //   * an iteration covers NBI = 2 row blocks (64 output channels): 4 independent accumulator chains per wave, half the barriers, and the
 //     fp16 results of a group leave through a per-wave LDS transposition as whole 128-byte lines (8 lanes x 16 B per pixel) instead of
 //     32-byte pieces of 32 different lines per store instruction (that alone cost 22 % of the old kernel);
-//   * weights are staged one iteration ahead through registers into an LDS double buffer, as before.
+//   * weights (and the bias of the iteration's row blocks) are staged one iteration ahead by LDS-DMA into an LDS double buffer: no staging
+//     registers, and no vector-memory result is consumed inside the loop (the old kernel's accumulator init from `bias` made the compiler wait
+//     vmcnt(0) - i.e. for the just-issued weight prefetch - in front of the first MFMA of every iteration).  A phase stagger of the first
+//     workgroup on each CU (tried: 0 / 8k / 16k / 32k cycles per class) changes nothing: the kernel is not HBM-burst-bound in its prologue.
 // Numerics are those of k_pw_kres_lds: same LayerNorm arithmetic, same fragment order of the hi and lo MFMAs per accumulator.
 #include "ira_kernels.h"
 #include "ira_device.h"

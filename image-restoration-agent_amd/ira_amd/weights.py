@@ -117,8 +117,15 @@ def seeded_tensor(seed: int, name: str, shape: tuple[int, ...]) -> np.ndarray:
     return (std * rng.standard_normal(shape)).astype(np.float32)
 
 
-def seeded_state_dict(cfg: RestormerConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
-    return OrderedDict((n, seeded_tensor(seed, n, s)) for n, s in state_dict_spec(cfg))
+def seeded_state_dict(cfg: RestormerConfig, seed: int = 0, residual_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """``residual_scale`` multiplies every branch's last 1x1 (attention and GDFN ``project_out``): the size of what each block adds to the
+    residual stream relative to the stream itself (the parity sweep of tests/golden/make_golden_sweep.py runs x0.25 / x1 / x4)."""
+    sd = OrderedDict((n, seeded_tensor(seed, n, s)) for n, s in state_dict_spec(cfg))
+    if residual_scale != 1.0:
+        for n in sd:
+            if n.endswith('.project_out.weight'):
+                sd[n] = (sd[n] * np.float32(residual_scale)).astype(np.float32)
+    return sd
 
 
 def to_torch(sd_np):

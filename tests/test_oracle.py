@@ -23,8 +23,24 @@ NET = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'net_*.
 HARNESS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'harness_*.npz')))
 
 
+SWEEP = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'sweep_*.npz')))
+
+
 def test_fixtures_present():
-    assert len(NET) >= 6 and len(HARNESS) >= 6
+    assert len(NET) >= 6 and len(HARNESS) >= 6 and len(SWEEP) == 18
+
+
+@pytest.mark.parametrize('path', [p for p in SWEEP if '_reduced_' in p or '_s25' in p], ids=lambda p: os.path.basename(p)[6:-4])
+def test_oracle_matches_reference_over_the_sweep(path):
+    """The oracle against the reference module at residual scales x0.25 / x1 / x4 and sigma 5 / 25 / 50 (all reduced cases, the full ones at
+    sigma 25: the CPU suite stays short; the GPU suite runs all 18)."""
+    z, cfg = _load(path)
+    sd = to_torch(seeded_state_dict(cfg, int(z['seed']), residual_scale=float(z['residual_scale'])))
+    out = O.restore_image(z['noisy'], sd, cfg.to_dict(), tile=int(z['tile']), tile_overlap=int(z['overlap']))
+    ref = z['restored']
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    assert abs(O.psnr_u8(out, z['clean']) - O.psnr_u8(ref, z['clean'])) < 1e-3
 
 
 @pytest.mark.parametrize('path', NET, ids=[os.path.basename(p)[4:-4] for p in NET])
