@@ -622,7 +622,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
 }
 
 // ---- Phi table: one copy per device, filled on first use
-static hipError_t phi_table(const float2** out) {
+hipError_t phi_table(const float2** out) {
     static float2* tabs[64] = {};
     static std::atomic<uint64_t> done{0};
     int dev = 0;

@@ -64,6 +64,8 @@ hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mod
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);
 
+// ira_ffn2.hip: the (Phi, slope) table of the GELU look-up, 1024 entries of float2 over [0, 6), one copy per device
+hipError_t phi_table(const float2** out);
 bool ffn2_supported(int C, int Hp);
 hipError_t launch_ffn2(hipStream_t st, const float* x, float* x_out, const void* v, const void* M, long m_tile_stride, const float* wo_b,
                        int ln_mode, int C, const void* Win, const float* bin, const float* dww, const float* dwb, const void* Wout,

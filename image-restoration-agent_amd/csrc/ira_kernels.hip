@@ -621,12 +621,13 @@ constexpr int DW_PX = 4;   // pixels per thread: 4 x 8 register block (8 x 8 ran
 
 __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, f16* __restrict__ qk,
-                                                    f16* __restrict__ v, int T, int H, int W, int C) {
-    const int WB = (W + 7) >> 3, XB = 2 * WB, G = (3 * C) >> 3, GQK = (2 * C) >> 3, HP = (H + 1) >> 1;
+                                                    f16* __restrict__ v, int T, int H, int W, int C, int g_lo) {
+    // channel groups g_lo .. 3C/8 - 1 (g_lo = 2C/8: the v third only, q and k being written by k_dwconv_qk_lines)
+    const int WB = (W + 7) >> 3, XB = 2 * WB, G = ((3 * C) >> 3) - g_lo, GQK = (2 * C) >> 3, HP = (H + 1) >> 1;
     const long total = (long)T * HP * XB * G;
     const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % G);
+    const int g = g_lo + (int)(idx % G);
     long rest = idx / G;
     const int xq = (int)(rest % XB); rest /= XB;     // 4-pixel block index along the (padded) row
     const int y0 = 2 * (int)(rest % HP);             // two output rows per thread
@@ -664,9 +665,54 @@ __global__ __launch_bounds__(256) void k_dwconv_qkv(const f16* __restrict__ in, 
     }
 }
 
+// q and k of the depthwise 3x3 in the pixel-minor layout [T][H][WB][2C][8], one thread = one (row, 8-pixel block, channel octet) = eight
+// 16-byte vectors = exactly ONE 128-byte line of the output, and consecutive work items own consecutive lines: the tensor is a linear
+// function of the item index.  k_dwconv_qkv's 4-pixel threads wrote that line as sixteen 8-byte pieces from two threads (64 lines per store
+// instruction); here a wave's 64 lines (8 KB) are transposed through LDS (slot XOR-swizzled by the lane's low bits: conflict-free both
+// ways) and leave as eight fully contiguous 1 KB stores.  Same tap order as dw_block: bitwise the same values.
+__global__ __launch_bounds__(256) void k_dwconv_qk_lines(const f16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         f16* __restrict__ qk, int T, int H, int W, int C) {
+    __shared__ __attribute__((aligned(16))) half8 stage[4][512];
+    const int WB = (W + 7) >> 3, GQK = (2 * C) >> 3;
+    const long total = (long)T * H * WB * GQK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long item = xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const long it = item < total ? item : total - 1;
+    const int g = (int)(it % GQK);
+    long rest = it / GQK;
+    const int xb = (int)(rest % WB); rest /= WB;
+    const int y = (int)(rest % H);
+    const int t = (int)(rest / H);
+    float acc[8][8];
+    dw_block<8>(in, w, bias, H, W, 3 * C, t, y, 8 * xb, g * 8, acc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        half8 o;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) o[p] = (8 * xb + p < W) ? (f16)acc[p][e] : (f16)0.f;
+        stage[wave][lane * 8 + (e ^ (lane & 7))] = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long item0 = item - lane;                                  // the wave's first item: its lines start at half8 index 8 * item0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int slot = 64 * i + lane, l2 = slot >> 3, e2 = slot & 7;
+        const half8 o = stage[wave][l2 * 8 + (e2 ^ (l2 & 7))];
+        if (item0 + l2 < total) ((half8*)qk)[item0 * 8 + slot] = o;
+    }
+}
+
+template <bool TAB>
 __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, f16* __restrict__ out,
-                                                     int T, int H, int W, int Hp) {
+                                                     int T, int H, int W, int Hp, const float2* __restrict__ phitab) {
+    // TAB: GELU as |a| Phi(|a|) + min(a, 0) with Phi from the 1024-entry (value, slope) table of ira_ffn2.hip staged in LDS: 10 vector
+    // instructions per value instead of the ~20 (one v_rcp, one v_exp) of gelu_erf, which cost as much as the nine taps
+    __shared__ float2 tab[TAB ? 1024 : 1];
+    if constexpr (TAB) {
+        for (int i = threadIdx.x; i < 512; i += 256) ((f32x4*)tab)[i] = ((const f32x4*)phitab)[i];
+        __syncthreads();
+    }
     const int XB = (W + DW_PX - 1) / DW_PX, G = Hp >> 3;
     const long total = (long)T * H * XB * G;
     const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -686,7 +732,17 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
         if (x0 + p < W) {
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(gelu_erf(a1[p][e]) * a2[p][e]);
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (TAB) {
+                    const float a = a1[p][e], aa = fabsf(a);
+                    const float tt = fminf(aa * (1024.0f / 6.0f), 1024.0f - 0.004f);
+                    const float2 en = tab[(int)tt];
+                    const float ph = fmaf(__builtin_amdgcn_fractf(tt), en.y, en.x);
+                    o[e] = (f16)(fmaf(aa, ph, fminf(a, 0.f)) * a2[p][e]);
+                } else {
+                    o[e] = (f16)(gelu_erf(a1[p][e]) * a2[p][e]);
+                }
+            }
             *(half8*)(dst + (long)p * Hp) = o;
         }
     }
@@ -1077,8 +1133,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
     constexpr int SH = (F + 3) / 4;
     constexpr int TH = 8 * PG, TW = 16, HX = TW + 2, NQ = (TH + 2) * HX;   // PG pixel groups per wave: rows 2w, 2w + 1 of each 8-row band
     constexpr int NE = NQ * 4, BI = (NE + 255) / 256;                  // float4 elements of one k-step of the halo tile
-    __shared__ __attribute__((aligned(16))) half8 wl[2][F][64];
-    __shared__ __attribute__((aligned(16))) half8 bt[2][2][2][NQ];    // [buffer][plane hi / lo][k half][halo pixel]
+    typedef half8 (*WlT)[F][64];
+    typedef half8 (*BtT)[2][2][NQ];
+    constexpr size_t WL_BYTES = sizeof(half8) * 2 * F * 64, BT_BYTES = sizeof(half8) * 2 * 2 * 2 * NQ;
+    __shared__ __attribute__((aligned(16))) char lds_all[WL_BYTES + BT_BYTES];
+    WlT wl = (WlT)lds_all;                                             // [2][F][64]
+    BtT bt = (BtT)(lds_all + WL_BYTES);                                // [buffer][plane hi / lo][k half][halo pixel]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int tiles_x = (Wd + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const long tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1196,6 +1256,79 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
             for (int i = 0; i < SH; ++i) nxt[i] = ld[i];
             if (tap == 8 && s + 1 < KT) bstore(bb ^ 1);
             __syncthreads();
+        }
+    }
+    if constexpr (MODE == 2 && PG == 1 && NBW % 2 == 0) if ((N & 15) == 0) {
+        // PixelShuffle(2) epilogue through LDS.  Output channel n of input pixel (y, x) is channel n >> 2 of output pixel (2y + (n >> 1 & 1),
+        // 2x + (n & 1)): straight from the accumulators that is one 4-byte store per value, 64 different cache lines per store
+        // instruction (96 instructions per lane at 6 row blocks - the up-convolutions spent most of their time here).  Each wave owns
+        // 2 x 16 input pixels = 4 x 32 output pixels; two row blocks at a time (16 output channels = 64 B per output pixel) go through the
+        // wave's own 9 KB of the (now dead) weight / pixel buffers and leave as 16-byte stores, 4 lanes per output pixel.
+        constexpr int PS = 18;                                   // floats per staged output pixel (16 + 2: the 16 lanes of a row hit 8 bank groups)
+        static_assert(WL_BYTES + BT_BYTES >= 4 * 128 * PS * 4, "staging must fit the main loop's buffers");
+        float* stg = (float*)lds_all + wave * 128 * PS;
+        const int N4 = N >> 2;
+        const int yo0 = 2 * (y0 + 2 * wave), xo0 = 2 * x0;       // first output row / column of this wave
+#pragma unroll
+        for (int pr = 0; pr < NBW / 2; ++pr) {
+#pragma unroll
+            for (int nbb = 0; nbb < 2; ++nbb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {           // sub = 2 sy + sx = n & 3; the lane's two values of this sub-pixel are channels cc, cc + 1
+                        const int orow = 2 * (r >> 4) + (sub >> 1), opx = 2 * pxx + (sub & 1);
+                        float2 v2;
+                        v2.x = acc[0][2 * pr + nbb][8 * u + sub]; v2.y = acc[0][2 * pr + nbb][8 * u + 4 + sub];
+                        *(float2*)(stg + (orow * 32 + opx) * PS + 8 * nbb + 4 * u + 2 * h) = v2;
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int piece = lane & 3;
+            const int cc0 = 8 * (nb0 + 2 * pr) + 4 * piece;       // first of this lane's 4 output channels
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int op = (lane >> 2) + 16 * i;              // output pixel 0..127 of the wave: row op >> 5, column op & 31
+                const int yo = yo0 + (op >> 5), xo = xo0 + (op & 31);
+                const float* sp = stg + op * PS + 4 * piece;
+                f32x4 v4; v4[0] = sp[0]; v4[1] = sp[1]; v4[2] = sp[2]; v4[3] = sp[3];
+                if (yo < 2 * H && xo < 2 * Wd && cc0 + 4 <= N4) *(f32x4*)(out + (((long)t * (2 * H) + yo) * (2 * Wd) + xo) * N4 + cc0) = v4;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+    if constexpr (MODE == 1) if (gridDim.y == 1) {
+        // PixelUnshuffle(2) epilogue through LDS.  A wave's 2 x 16 input pixels are exactly 8 output pixels with all their 4 N channels
+        // (channel 4 n + 2 (y & 1) + (x & 1)), and those 8 pixels are consecutive in memory: 8 x 4N floats in one run.  From the
+        // accumulators that is one 4-byte store per value at a 16-byte stride; staged, it is whole 16-byte pieces of consecutive lines.
+        const int N4 = 4 * N, PSU = N4 + 4;                       // floats per staged output pixel (+4: the 8 pixels start in different banks)
+        float* stg = (float*)lds_all + wave * 8 * PSU;
+        const bool fits = (size_t)4 * 8 * PSU * 4 <= WL_BYTES + BT_BYTES;
+        if (fits) {
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                const int sub = 2 * (r >> 4) + (pxx & 1), opx = pxx >> 1;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = 32 * nb + 16 * u + 8 * h + j;
+                            if (n < N) stg[opx * PSU + 4 * n + sub] = acc[g][nb][8 * u + j];
+                        }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int yo = (y0 + 8 * g) / 2 + wave, xo0 = x0 / 2;
+                const int npiece = 8 * N;                         // float4 pieces of the wave's 8 output pixels
+                for (int e = lane; e < npiece; e += 64) {
+                    const int op = e / N, c4 = e - op * N;        // output pixel, piece within its 4N floats
+                    const float* sp = stg + op * PSU + 4 * c4;
+                    f32x4 v4; v4[0] = sp[0]; v4[1] = sp[1]; v4[2] = sp[2]; v4[3] = sp[3];
+                    if (yo < (H >> 1) && xo0 + op < (Wd >> 1)) *(f32x4*)(out + (((long)t * (H >> 1) + yo) * (Wd >> 1) + xo0 + op) * N4 + 4 * c4) = v4;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            return;
         }
     }
 #pragma unroll
@@ -1582,9 +1715,15 @@ hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1
 hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias, void* qk, void* v,
                              int T, int H, int W, int C) {
     if (C % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)T * ((H + 1) / 2) * (2 * ((W + 7) / 8)) * (3 * C / 8);      // two output rows per thread
+    static const int lines_env = env_int("IRA_DWQK_LINES", 1);
+    const int g_lo = lines_env ? 2 * C / 8 : 0;
+    if (lines_env) {
+        const long items = (long)T * H * ((W + 7) / 8) * (2 * C / 8);
+        hipLaunchKernelGGL(k_dwconv_qk_lines, dim3(grid1d(items, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)qk, T, H, W, C);
+    }
+    const long total = (long)T * ((H + 1) / 2) * (2 * ((W + 7) / 8)) * (3 * C / 8 - g_lo);      // two output rows per thread
     hipLaunchKernelGGL(k_dwconv_qkv, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)qk,
-                       (f16*)v, T, H, W, C);
+                       (f16*)v, T, H, W, C, g_lo);
     return hipGetLastError();
 }
 
@@ -1592,8 +1731,15 @@ hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, co
                               int H, int W, int Hp) {
     if (Hp % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)T * H * ((W + DW_PX - 1) / DW_PX) * (Hp / 8);
-    hipLaunchKernelGGL(k_dwconv_gate, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out,
-                       T, H, W, Hp);
+    static const int tab_env = env_int("IRA_GATE_TAB", 1);
+    if (tab_env) {
+        const float2* tab = nullptr;
+        if (hipError_t e = phi_table(&tab); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_dwconv_gate<true>, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out, T, H, W, Hp, tab);
+    } else {
+        hipLaunchKernelGGL(k_dwconv_gate<false>, dim3(grid1d(total, 256)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out, T, H, W, Hp,
+                           (const float2*)nullptr);
+    }
     return hipGetLastError();
 }
 
@@ -1674,7 +1820,8 @@ static hipError_t conv3x3_dispatch(hipStream_t st, const float* in, const f16* W
     // SwinIR upsampler and the 2-block convolutions
     static const int tile_min_nbw = env_int("IRA_CONV_TILE_MINNBW", 3), tile_min_kt = env_int("IRA_CONV_TILE_MINKT", 6);
     static const int tile_small = env_int("IRA_CONV_TILE_SMALL", 1);     // 1-2 row blocks: 2 pixel groups per wave
-    const bool big = NBW >= tile_min_nbw && (K >> 4) >= tile_min_kt, small = tile_small && NBW <= 2 && (K >> 4) >= 4;
+    static const int small_min_kt = env_int("IRA_CONV_TILE_SMALL_MINKT", 3);
+    const bool big = NBW >= tile_min_nbw && (K >> 4) >= tile_min_kt, small = tile_small && NBW <= 2 && (K >> 4) >= small_min_kt;
     if (tile_env && lds_env && (big || small)) {
         static const int pg34 = env_int("IRA_CONV_TILE_PG34", 1);
         const int pg = NBW <= 2 ? 2 : ((NBW == 3 || NBW == 4) ? pg34 : 1);

@@ -270,6 +270,8 @@ def conv3_pack(w):
     (1, 192, 96, 1, 4, 4),
     (2, 32, 64, 2, 3, 5),      # Upsample: conv + PixelShuffle (:181-189)
     (2, 384, 768, 1, 2, 3),
+    (2, 96, 192, 2, 11, 21),   # six row blocks through the LDS-staged PixelShuffle epilogue, ragged tiles in both directions
+    (1, 96, 48, 2, 10, 22),    # Downsample with ragged 8 x 16 tiles
     (2, 64, 256, 1, 4, 4),     # NB=8: two n-chunks, the second partial
     (3, 96, 3, 2, 8, 9),       # output conv + input skip (:281)
     (3, 32, 1, 1, 5, 5),
