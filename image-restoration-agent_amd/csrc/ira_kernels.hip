@@ -713,15 +713,19 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
         for (int i = threadIdx.x; i < 512; i += 256) ((f32x4*)tab)[i] = ((const f32x4*)phitab)[i];
         __syncthreads();
     }
+    // A workgroup = 64 consecutive (4-pixel block, channel octet) items of FOUR consecutive rows, one row per wave: the six input rows the
+    // band needs are then shared through L1 by waves that run together (with one row per workgroup every input row came from L2 three
+    // times: 9 KB of L2 reads per pixel for 2 KB of data - the kernel ran at the L2's bandwidth, not HBM's)
     const int XB = (W + DW_PX - 1) / DW_PX, G = Hp >> 3;
-    const long total = (long)T * H * XB * G;
-    const long idx = xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % G);
-    long rest = idx / G;
-    const int xq = (int)(rest % XB); rest /= XB;
-    const int y = (int)(rest % H);
-    const int t = (int)(rest / H);
+    const int row_items = XB * G, chunks = (row_items + 63) >> 6, bands = (H + 3) >> 2;
+    const long bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int chunk = (int)(bid % chunks);
+    const int band = (int)((bid / chunks) % bands);
+    const int t = (int)(bid / ((long)chunks * bands));
+    const int item = chunk * 64 + (threadIdx.x & 63);
+    const int y = band * 4 + (threadIdx.x >> 6);
+    if (item >= row_items || y >= H) return;
+    const int g = item % G, xq = item / G;
     const int x0 = xq * DW_PX;
     float a1[DW_PX][8], a2[DW_PX][8];
     dw_block<DW_PX>(in, w, bias, H, W, 2 * Hp, t, y, x0, g * 8, a1);
@@ -744,6 +748,98 @@ __global__ __launch_bounds__(256) void k_dwconv_gate(const f16* __restrict__ in,
                 }
             }
             *(half8*)(dst + (long)p * Hp) = o;
+        }
+    }
+}
+
+// The same gate with the depthwise WEIGHTS in LDS.  k_dwconv_gate's lanes are channel octets, so every tap's 16 weights are two 16-byte
+// loads per lane: as many load instructions as the pixels themselves (36 + 36 per 4 output pixels), and 36 KB of weights (2 Hp = 1024
+// channels) do not stay in the 32 KB L1.  Here a workgroup stages the weights of its 64 channel octets once (18 taps x 64 x 32 B = 36 KB,
+// lane-contiguous: conflict-free reads) and its four waves (one image row each) walk along the row in 4-pixel steps.
+template <bool TAB>
+__global__ __launch_bounds__(256) void k_dwconv_gate_row(const f16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         f16* __restrict__ out, int T, int H, int W, int Hp, int nseg, const float2* __restrict__ phitab) {
+    __shared__ __attribute__((aligned(16))) float wsm[18][64][8];
+    __shared__ float2 tab[TAB ? 1024 : 1];
+    const int G = Hp >> 3, gchunks = (G + 63) >> 6, bands = (H + 3) >> 2, Cs = 2 * Hp;
+    const long bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int seg = (int)(bid % nseg);
+    const int gchunk = (int)((bid / nseg) % gchunks);
+    const int band = (int)((bid / ((long)nseg * gchunks)) % bands);
+    const int t = (int)(bid / ((long)nseg * gchunks * bands));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 18 * 64 * 2; i += 256) {               // 16-byte pieces: [tap18][octet][half of the octet]
+        const int hf = i & 1, gl = (i >> 1) & 63, tp = i >> 7;
+        const int gg = min(gchunk * 64 + gl, G - 1);
+        const int ch = (tp < 9 ? 0 : Hp) + 8 * gg + 4 * hf;
+        *(f32x4*)&wsm[tp][gl][4 * hf] = *(const f32x4*)(w + (long)(tp < 9 ? tp : tp - 9) * Cs + ch);
+    }
+    if constexpr (TAB) {
+        for (int i = threadIdx.x; i < 512; i += 256) ((f32x4*)tab)[i] = ((const f32x4*)phitab)[i];
+    }
+    __syncthreads();
+    const int g = gchunk * 64 + lane, y = band * 4 + wave;
+    if (g >= G || y >= H) return;
+    const int XB = (W + 3) >> 2, per = (XB + nseg - 1) / nseg;
+    const int xq_lo = seg * per, xq_hi = min(XB, xq_lo + per);
+    float b1[8], b2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { b1[e] = bias ? bias[8 * g + e] : 0.f; b2[e] = bias ? bias[Hp + 8 * g + e] : 0.f; }
+    for (int xq = xq_lo; xq < xq_hi; ++xq) {
+        const int x0 = 4 * xq;
+        float a1[4][8], a2[4][8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a1[p][e] = 0.f; a2[p][e] = 0.f; }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+            const f16* rowp = in + ((long)(t * H + yy) * W) * Cs + 8 * g;
+            half8 v1[6], v2[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int xx = x0 - 1 + i;
+                const bool ok = xx >= 0 && xx < W;
+                v1[i] = ok ? *(const half8*)(rowp + (long)xx * Cs) : zero8();
+                v2[i] = ok ? *(const half8*)(rowp + (long)xx * Cs + Hp) : zero8();
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x4 w1l = *(const f32x4*)&wsm[dy * 3 + dx][lane][0], w1h = *(const f32x4*)&wsm[dy * 3 + dx][lane][4];
+                const f32x4 w2l = *(const f32x4*)&wsm[9 + dy * 3 + dx][lane][0], w2h = *(const f32x4*)&wsm[9 + dy * 3 + dx][lane][4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a1[p][e] = fmaf((float)v1[p + dx][e], w1l[e], a1[p][e]);
+                        a1[p][4 + e] = fmaf((float)v1[p + dx][4 + e], w1h[e], a1[p][4 + e]);
+                        a2[p][e] = fmaf((float)v2[p + dx][e], w2l[e], a2[p][e]);
+                        a2[p][4 + e] = fmaf((float)v2[p + dx][4 + e], w2h[e], a2[p][4 + e]);
+                    }
+            }
+        }
+        f16* dst = out + ((long)(t * H + y) * W + x0) * Hp + g * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (x0 + p < W) {
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = a1[p][e] + b1[e], bb = a2[p][e] + b2[e];
+                    if constexpr (TAB) {
+                        const float aa = fabsf(a);
+                        const float tt = fminf(aa * (1024.0f / 6.0f), 1024.0f - 0.004f);
+                        const float2 en = tab[(int)tt];
+                        const float ph = fmaf(__builtin_amdgcn_fractf(tt), en.y, en.x);
+                        o[e] = (f16)(fmaf(aa, ph, fminf(a, 0.f)) * bb);
+                    } else {
+                        o[e] = (f16)(gelu_erf(a) * bb);
+                    }
+                }
+                *(half8*)(dst + (long)p * Hp) = o;
+            }
         }
     }
 }
@@ -1730,8 +1826,17 @@ hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, con
 hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, const float* bias, void* out, int T,
                               int H, int W, int Hp) {
     if (Hp % 8 != 0) return hipErrorInvalidValue;
-    const long total = (long)T * H * ((W + DW_PX - 1) / DW_PX) * (Hp / 8);
-    static const int tab_env = env_int("IRA_GATE_TAB", 1);
+    const long total = (long)T * ((H + 3) / 4) * ((((W + DW_PX - 1) / DW_PX) * (Hp / 8) + 63) / 64) * 256;      // threads: workgroups x 256
+    static const int tab_env = env_int("IRA_GATE_TAB", 1), row_env = env_int("IRA_GATE_ROW", 1);
+    if (row_env && Hp >= 64) {
+        const float2* tab = nullptr;
+        if (hipError_t e = phi_table(&tab); e != hipSuccess) return e;
+        const int gchunks = (Hp / 8 + 63) / 64, bands = (H + 3) / 4, XB = (W + 3) / 4;
+        const long base = (long)T * bands * gchunks;
+        int nseg = (int)std::min<long>(std::max<long>(1, (1024 + base - 1) / base), std::max(1, XB / 4));    // >= 4 steps per segment: the weight staging is per workgroup
+        hipLaunchKernelGGL(k_dwconv_gate_row<true>, dim3((unsigned)(base * nseg)), dim3(256), 0, st, (const f16*)in, w, bias, (f16*)out, T, H, W, Hp, nseg, tab);
+        return hipGetLastError();
+    }
     if (tab_env) {
         const float2* tab = nullptr;
         if (hipError_t e = phi_table(&tab); e != hipSuccess) return e;

@@ -192,17 +192,21 @@ def test_dwconv_qkv(ctx, C, T, H, W):
     close(qk.cpu().float(), q_ref, 2e-3)
 
 
-@pytest.mark.parametrize('Hp,T,H,W', [(64, 2, 6, 9), (128, 1, 4, 24), (32, 1, 2, 3)])
-def test_dwconv_gate(ctx, Hp, T, H, W):
+@pytest.mark.parametrize('Hp,T,H,W,with_bias', [(64, 2, 6, 9, False), (128, 1, 4, 24, False), (32, 1, 2, 3, False),
+                                                (1024, 1, 5, 10, True),      # k_dwconv_gate_row: two chunks of 64 channel octets, rows not a multiple of 4
+                                                (512, 2, 9, 37, True)])       # ragged last 4-pixel step, several row segments per band
+def test_dwconv_gate(ctx, Hp, T, H, W, with_bias):
     g = torch.Generator().manual_seed(Hp + W)
     x = r16(torch.randn(T, 2 * Hp, H, W, generator=g))
     w = torch.randn(2 * Hp, 1, 3, 3, generator=g) / 3
-    d = F.conv2d(x, w, padding=1, groups=2 * Hp)            # restormer_arch.py:84,90
+    b = torch.randn(2 * Hp, generator=g) * 0.2 if with_bias else None
+    d = F.conv2d(x, w, b, padding=1, groups=2 * Hp)         # restormer_arch.py:84,90
     ref = (F.gelu(d[:, :Hp]) * d[:, Hp:]).permute(0, 2, 3, 1).contiguous()   # :91
     xd = dev(x.permute(0, 2, 3, 1).half())
     wd = dev(w.view(2 * Hp, 9).t())
+    bd = dev(b) if with_bias else None
     out = torch.full((T, H, W, Hp), float('nan'), dtype=torch.float16).cuda()
-    rc = ctx._lib.ira_op_dwconv_gate(ctx.handle, ptr(xd), ptr(wd), None, ptr(out), T, H, W, Hp)
+    rc = ctx._lib.ira_op_dwconv_gate(ctx.handle, ptr(xd), ptr(wd), ptr(bd), ptr(out), T, H, W, Hp)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     close(out.cpu().float(), ref, 2e-3)
 
