@@ -61,6 +61,11 @@ bool pw_wide_supported(int K, long npx);
 hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W, const float* bias, void* y, int y_stride,
                           int n_store, int NB, int T, int P, float eps, int ln_n, int act);
 
+// ira_nres_wide.hip: 1x1 + residual for N = 192 / 384 (fp16 pixels, one input tensor) in 256-pixel workgroups
+bool nres_wide_supported(int K, int N, int NB, int T, int P, long w_tile_stride);
+hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
+                            int N, int NB, int T, int P);
+
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);
 

@@ -1797,6 +1797,8 @@ hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1
                           long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T,
                           int P) {
     if (K0 % 16 != 0 || K1 % 16 != 0 || N % 8 != 0 || NB * 32 < N) return hipErrorInvalidValue;
+    if ((x1 == nullptr || K1 == 0) && !in_f32 && nres_wide_supported(K0, N, NB, T, P, w_tile_stride))
+        return launch_nres_wide(st, x0, K0, W, w_tile_stride, bias, resid, y, N, NB, T, P);
     if ((x1 == nullptr || K1 == 0) && pw_gemm_supported(K0, N, NB))      // one input tensor: both operands through LDS (ira_nafnet.hip)
         return launch_pw_gemm(st, x0, in_f32, K0, W, w_tile_stride, bias, resid, y, N, NB, T, P);
     const f16* Wh = (const f16*)W;

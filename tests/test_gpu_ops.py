@@ -117,6 +117,10 @@ def test_pw_kres(ctx, K, N, ln, in_f32, T, P, with_bias):
     (48, 48, True, 48, 2, 31, False, False, False),
     (128, 0, True, 160, 2, 300, True, False, True),    # k_pw_gemm: 5 row blocks as 3 + 2 (clamped partial chunk), several workgroups per image, fp32 pixels
     (96, 0, False, 224, 1, 257, False, False, True),   # k_pw_gemm: 7 row blocks as 4 + 3, ragged last workgroup
+    (512, 0, False, 192, 2, 16401, True, False, False),  # k_nres_wide (>= 32 768 px, N = 192): project_out + residual at level 3, ragged last group of each tile
+    (192, 0, False, 192, 3, 11000, True, True, False),   # k_nres_wide: attention apply, one matrix per tile, tiles that are no multiple of 256 px
+    (1024, 0, False, 384, 1, 33000, True, False, True),  # k_nres_wide: N = 384 as two halves, bias, 16 stages
+    (256, 0, False, 184, 1, 32800, False, False, False), # k_nres_wide: N not a multiple of 32 (partial last row block), no residual
 ])
 def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
     g = torch.Generator().manual_seed(K0 + 3 * N + K1)
