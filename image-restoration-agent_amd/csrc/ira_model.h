@@ -130,6 +130,9 @@ struct ira_model {
     bool strip_rccl = false;
     char* strip_buf = nullptr; size_t strip_buf_bytes = 0;      // library-owned staging of the band exchange (RCCL mode)
     float* dist_tiles = nullptr; size_t dist_tiles_bytes = 0;   // all tiles of a frame (all-gather destination)
+    // grow-only device buffers of the host-image entry points (ira_restore_u8, ira_restore_padcrop_u8): frame in, frame out, tiles, ...
+    void* io[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t io_bytes[5] = {0, 0, 0, 0, 0};
     int* strip_desc = nullptr;                                  // device copy of the band descriptor of ira_strip_restore_u8_device
     int strip_desc_host[6] = {0, 0, 0, 0, 0, 0};
     void *qkvp, *qk, *v, *hp, *g, *M;

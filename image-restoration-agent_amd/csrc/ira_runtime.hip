@@ -9,6 +9,18 @@ namespace ira_rt {
 
 thread_local std::string g_err;
 
+// Slot `k` of the handle's I/O buffers, at least `bytes` long (grow-only: a service that restores frames of one size allocates once)
+int ensure_io(ira_model* m, int k, size_t bytes, void** out) {
+    if (!m->io[k] || bytes > m->io_bytes[k]) {
+        if (m->io[k]) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->io[k])); m->io[k] = nullptr; m->io_bytes[k] = 0; }
+        hipError_t e = hipMalloc(&m->io[k], bytes);
+        if (e != hipSuccess) { m->io[k] = nullptr; return m->fail(IRA_ERR_OOM, "I/O buffer hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        m->io_bytes[k] = bytes;
+    }
+    *out = m->io[k];
+    return IRA_OK;
+}
+
 int ensure_scratch(ira_model* m, size_t bytes) {
     if (m->hs && bytes <= m->hs_bytes) return IRA_OK;
     if (m->hs) { HIP_TRY(m, hipStreamSynchronize(m->st)); HIP_TRY(m, hipFree(m->hs)); m->hs = nullptr; m->hs_bytes = 0; }
@@ -380,6 +392,7 @@ int ira_model_destroy(ira_model_t* m) {
     if (m->strip_buf) hipFree(m->strip_buf);
     if (m->strip_desc) hipFree(m->strip_desc);
     if (m->dist_tiles) hipFree(m->dist_tiles);
+    for (int k = 0; k < 5; ++k) if (m->io[k]) hipFree(m->io[k]);
     if (m->ws) hipFree(m->ws);
     if (m->xr_up) hipFree(m->xr_up);
     if (m->hs) hipFree(m->hs);
@@ -702,14 +715,12 @@ int ira_restore_u8(ira_model_t* m, const uint8_t* in, int h, int w, int c, int t
     const size_t obytes = fbytes * p.scale * p.scale;
     const size_t tbytes = (size_t)nt * p.th * p.tw * c * 4 * p.scale * p.scale;
     uint8_t *fin = nullptr, *fout = nullptr; float* tiles = nullptr;
-    auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tiles) hipFree(tiles); };
+    auto cleanup = [&]() {};                                   // the buffers belong to the handle (ensure_io): nothing to free per call
     hipError_t e;
-    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, obytes)) != hipSuccess ||
-        (e = hipMalloc((void**)&tiles, tbytes)) != hipSuccess) {
-        cleanup();
-        return m->fail(IRA_ERR_OOM, "ira_restore_u8: hipMalloc: %s", hipGetErrorString(e));
-    }
-    int rc = IRA_OK;
+    int rc = ensure_io(m, 0, fbytes, (void**)&fin);
+    if (rc == IRA_OK) rc = ensure_io(m, 1, obytes, (void**)&fout);
+    if (rc == IRA_OK) rc = ensure_io(m, 2, tbytes, (void**)&tiles);
+    if (rc != IRA_OK) return rc;
     do {
         if ((e = hipMemcpyAsync(fin, in, fbytes, hipMemcpyHostToDevice, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
         if ((rc = restore_tiles_enqueue(m, fin, h, w, c, p, 0, nt, tiles)) != IRA_OK) break;
@@ -754,7 +765,7 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
     const int sc = model_scale(m);      // tile_process with scale (:72-76,117-133)
     const size_t fbytes = (size_t)h * w * c, obytes = fbytes * sc * sc;
     uint8_t *fin = nullptr, *fout = nullptr; float *tin = nullptr, *tout = nullptr; int* ddev = nullptr;
-    auto cleanup = [&]() { if (fin) hipFree(fin); if (fout) hipFree(fout); if (tin) hipFree(tin); if (tout) hipFree(tout); if (ddev) hipFree(ddev); };
+    auto cleanup = [&]() {};                                   // handle-owned buffers (ensure_io)
     size_t max_batch_elems = 0, max_desc = 0;
     std::map<std::pair<int, int>, int> batch_of;
     for (auto& kv : classes) {
@@ -766,13 +777,12 @@ int ira_restore_padcrop_u8(ira_model_t* m, const uint8_t* in, int h, int w, int 
         max_desc = std::max(max_desc, kv.second.size());
     }
     hipError_t e;
-    if ((e = hipMalloc((void**)&fin, fbytes)) != hipSuccess || (e = hipMalloc((void**)&fout, obytes)) != hipSuccess ||
-        (e = hipMalloc((void**)&tin, max_batch_elems * 4)) != hipSuccess || (e = hipMalloc((void**)&tout, max_batch_elems * 4 * sc * sc)) != hipSuccess ||
-        (e = hipMalloc((void**)&ddev, max_desc * sizeof(D))) != hipSuccess) {
-        cleanup();
-        return m->fail(IRA_ERR_OOM, "ira_restore_padcrop_u8: hipMalloc: %s", hipGetErrorString(e));
-    }
-    int rc = IRA_OK;
+    int rc = ensure_io(m, 0, fbytes, (void**)&fin);
+    if (rc == IRA_OK) rc = ensure_io(m, 1, obytes, (void**)&fout);
+    if (rc == IRA_OK) rc = ensure_io(m, 2, max_batch_elems * 4, (void**)&tin);
+    if (rc == IRA_OK) rc = ensure_io(m, 3, max_batch_elems * 4 * sc * sc, (void**)&tout);
+    if (rc == IRA_OK) rc = ensure_io(m, 4, max_desc * sizeof(D), (void**)&ddev);
+    if (rc != IRA_OK) return rc;
     do {
         if ((e = hipMemcpyAsync(fin, in, fbytes, hipMemcpyHostToDevice, m->st)) != hipSuccess) { rc = m->fail(IRA_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
         for (auto& kv : classes) {
@@ -848,6 +858,7 @@ int ira_memory_bytes(ira_model_t* m, size_t* bytes) {
     ENTER(m);
     if (!bytes) return m->fail(IRA_ERR_ARG, "NULL");
     *bytes = m->wbytes + m->ws_bytes + m->hs_bytes;
+    for (int k = 0; k < 5; ++k) *bytes += m->io_bytes[k];
     return IRA_OK;
 }
 

@@ -69,7 +69,8 @@ def test_subtask_to_task(subtask, task, cache):
 def test_executor_registry_and_directory_protocol(tmp_path, cache):
     ex = T.build_executor(cache)
     assert ex.subtasks == {'denoising', 'motion deblurring', 'defocus deblurring', 'deraining', 'super-resolution',
-                           'jpeg compression artifact removal', 'dehazing'}
+                           'jpeg compression artifact removal', 'dehazing', 'brightening'}
+    assert [t.tool_name for t in ex.toolbox_router['brightening']] == ['histogram_equalization', 'gamma_correction', 'constant_shift']
     # reference order, minus the tools this backend does not build (denoising/__init__.py:12-19, motion_deblurring :10-15, deraining :10-15)
     assert [t.tool_name for t in ex.toolbox_router['denoising']] == ['xrestormer', 'swinir_15', 'swinir_50', 'mprnet', 'restormer']
     assert [t.tool_name for t in ex.toolbox_router['motion deblurring']] == ['restormer', 'mprnet', 'xrestormer']
