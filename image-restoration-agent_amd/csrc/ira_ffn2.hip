@@ -130,7 +130,8 @@ IRA_DEV float gelu_gate_tab(float a, float b, const float2* tab) {
 }  // namespace
 
 // DBG (diagnostic builds of ONE instantiation, selected with IRA_FFN2_DBG at launch; results are wrong or slower, never shipped on a
-// product path): 1 = unit weights are constants (no scalar loads), 2 = no vector work at all, 3 = no project_in MFMAs, 4 = s_memtime stamps
+// product path): 1 = unit weights are constants (no scalar loads), 2 = no vector work at all, 3 = no project_in MFMAs, 4 = s_memtime stamps,
+// 12 = 2 + no hidden write-out, 13 = 12 + no project_out MFMAs, 14 = 13 + no project_in MFMAs (barriers, weight loads and LDS fragment reads only)
 __device__ unsigned long long g_ffn2_stamps[2][64];
 
 template <int C, int LN, bool BIN, bool CB, bool FOLD, int DBG = 0>
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             const int hy = id / PPR, wi = id - hy * PPR, hx = wi / (C / 4), ch = wi - hx * (C / 4);
             if (id < NPIECE) *(f32x4*)(xs + (long)(hy * PW + hx) * XS + 4 * ch) = piece[it];
         }
+        STAMP();
         __syncthreads();                                                    // (1) done
+        STAMP();
         auto take_group = [&](f32x16 (&acc)[NBC], int g) {
             const int q = group_q(g, r);
             const float* src = xs + (long)(q < 0 ? 0 : q) * XS;
@@ -263,7 +266,9 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         };
         if (haveA) take_group(accA, ga);
         if (isCc) take_group(accB, gb);
+        STAMP();
         __syncthreads();                                                    // (2) done: the staging area is dead
+        STAMP();
         if (FOLD) {
             const half8* Mg = (const half8*)(M + (long)t * m_stride);
             for (int i = tid; i < 2 * NBC * KS * 64; i += 512) Mlds[i] = Mg[i];
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         }
         f32x16 accp[1];
         auto write_out = [&](const f32x16& acc, f16* hp, int gi) {
-            if (DBG == 7) { asm volatile("" :: "v"(acc)); return; }
+            if (DBG == 7 || DBG == 12 || DBG == 13 || DBG == 14 || DBG == 15 || DBG == 16) { asm volatile("" :: "v"(acc)); return; }
             const int q = pq[gi];
             if (q >= 0 && pin[gi]) {
                 // convert in pairs (v_cvt_pk_f16_f32, round to nearest even).  Pixels outside the image (the zero padding of the depthwise
@@ -479,9 +484,9 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             }
         };
         auto interval = [&](auto PRc, auto UNc, auto PARc, int i) {
-            constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value && DBG != 2;
+            constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value && DBG != 2 && DBG != 12 && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16;
             constexpr int par = decltype(PARc)::value;                 // i & 1: the weight register set of this interval
-            if (pr && i + 1 < NCH) load_win(i + 1, par ^ 1);
+            if (pr && i + 1 < NCH && (DBG != 16 || i == 0)) load_win(i + 1, par ^ 1);
             f16* hp = hpbuf + (size_t)(i & 1) * PHW * HPS;
             const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;       // the unit reads chunk i-1's buffer
             const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
                 if (pr && t < 8) {
 #pragma unroll
-                    for (int k = 0; k < KPS; ++k) bq[sl ^ 1][k] = xnl[((wave + 4 * ((t + 1) / 3)) * KS + KPS * ((t + 1) % 3) + k) * 64 + lane];
+                    for (int k = 0; k < KPS; ++k) { if (DBG == 15) bq[sl ^ 1][k] = bq[sl][k]; else bq[sl ^ 1][k] = xnl[((wave + 4 * ((t + 1) / 3)) * KS + KPS * ((t + 1) % 3) + k) * 64 + lane]; }
                 }
                 IRA_PIN();
                 if (un && t == 5) unit_gelu_a(0);
@@ -520,10 +525,10 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
 #pragma unroll
                     for (int k = 0; k < KPS; ++k) {
                         const int ks = KPS * (t % 3) + k;
-                        if (DBG != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[par][ks], bq[sl][k], acc, 0, 0, 0);
+                        if (DBG != 3 && DBG != 14) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[par][ks], bq[sl][k], acc, 0, 0, 0);
                         if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k : 0, t); if (KPS == 1) unit_fma4(sl, 1, t); }
                         IRA_PIN();
-                        if (DBG != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[par][ks], bq[sl][k], acc, 0, 0, 0);
+                        if (DBG != 3 && DBG != 14) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[par][ks], bq[sl][k], acc, 0, 0, 0);
                         if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k + 1 : 2, t); if (KPS == 1) unit_fma4(sl, 3, t); }
                         IRA_PIN();
                     }
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     STAMP();
     half8 fA, fB;
     auto cinterval = [&](auto UNc, auto COc, auto PARc, int i) {
-        constexpr bool un_ = decltype(UNc)::value, un = un_ && DBG != 2, co = decltype(COc)::value;
+        constexpr bool un_ = decltype(UNc)::value, un = un_ && DBG != 2 && DBG != 12 && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16, co = decltype(COc)::value && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16;
         constexpr int par = decltype(PARc)::value;                     // (i - 2) & 1 = i & 1: the weight register set chunk i - 2 was loaded into
         if (un_) load_wout(i - 1, par ^ 1);                            // chunk i - 1 is consumed in the next interval
         const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;
@@ -692,7 +697,7 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
                            dww, dwb, Wout, bout, tab, T, H, W, Hp, stagger);                                                                    \
         return hipGetLastError();                                                                                                               \
     }
-        IRA_DBG_LAUNCH(1) IRA_DBG_LAUNCH(2) IRA_DBG_LAUNCH(3) IRA_DBG_LAUNCH(4) IRA_DBG_LAUNCH(5) IRA_DBG_LAUNCH(6) IRA_DBG_LAUNCH(7) IRA_DBG_LAUNCH(8) IRA_DBG_LAUNCH(9)
+        IRA_DBG_LAUNCH(1) IRA_DBG_LAUNCH(2) IRA_DBG_LAUNCH(3) IRA_DBG_LAUNCH(4) IRA_DBG_LAUNCH(5) IRA_DBG_LAUNCH(6) IRA_DBG_LAUNCH(7) IRA_DBG_LAUNCH(8) IRA_DBG_LAUNCH(9) IRA_DBG_LAUNCH(12) IRA_DBG_LAUNCH(13) IRA_DBG_LAUNCH(14) IRA_DBG_LAUNCH(15) IRA_DBG_LAUNCH(16)
 #undef IRA_DBG_LAUNCH
     }
     hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
