@@ -38,7 +38,12 @@ class RestormerService:
             raise ValueError(f"Not supported task {task}")
         self.TASK = task
         self.weight_dir = weight_dir or os.environ.get('IRA_RESTORMER_WEIGHTS', '')
-        self._cache = cache or (BackendCache(device=device, weight_dir=self.weight_dir) if weight_dir else default_cache())
+        if cache is None:
+            dflt = default_cache()
+            # the process-wide cache only when it lives on the requested device; a service asked for another GPU (or given a weight
+            # directory) gets a cache of its own there
+            cache = dflt if (not weight_dir and dflt.device == device) else BackendCache(device=device, weight_dir=self.weight_dir or None)
+        self._cache = cache
         self.models = self._cache.models
         self.device = f'hip:{self._cache.device}'
         self.img_multiple_of = 8

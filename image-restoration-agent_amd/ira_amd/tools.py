@@ -115,28 +115,29 @@ def seeded_state_dict_loader(seed: int = 0) -> Callable:
     return load
 
 
-class BackendCache:
-    """task -> RestormerBackend on one device; plays the role of RestormerService.models
-    (model_serving.py:57,101-105: 'model has been loaded, use cache')."""
+class ModelCache:
+    """key -> backend on one device, built on first use and kept for the life of the process; plays the role of
+    RestormerService.models (model_serving.py:57,101-105: 'model has been loaded, use cache').  One implementation for every
+    model family: a subclass only says how a key turns into (config, state dict) and which backend class holds them."""
+    backend_name = ''                      # class in ira_amd.backend
+    default_loader: Optional[Callable] = None
 
     def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
                  backend_factory: Optional[Callable] = None):
-        self.device = device
-        self.loader = state_dict_loader or default_state_dict_loader
-        self.weight_dir = weight_dir
+        self.device, self.weight_dir = device, weight_dir
+        self.loader = state_dict_loader or type(self).default_loader
         self.factory = backend_factory
         self.models: dict = {}
 
-    def get(self, task: str):
-        if task not in self.models:
-            cfg = task_config(task)
-            sd = self.loader(task, self.weight_dir)
+    def _get(self, key, make_cfg: Callable, load_sd: Callable):
+        if key not in self.models:
+            cfg, sd = make_cfg(), load_sd()
             if self.factory is not None:
-                self.models[task] = self.factory(cfg, sd, self.device)
+                self.models[key] = self.factory(cfg, sd, self.device)
             else:
-                from .backend import RestormerBackend
-                self.models[task] = RestormerBackend(cfg, sd, device=self.device)
-        return self.models[task]
+                from . import backend
+                self.models[key] = getattr(backend, self.backend_name)(cfg, sd, device=self.device)
+        return self.models[key]
 
     def close(self):
         for be in self.models.values():
@@ -144,20 +145,36 @@ class BackendCache:
                 be.close()
         self.models.clear()
 
+    @classmethod
+    def default(cls):
+        """The process-wide cache of this family on $IRA_DEVICE / $LOCAL_RANK (created on first use)."""
+        if _DEFAULTS.get(cls) is None:
+            _DEFAULTS[cls] = cls(device=_default_device())
+        return _DEFAULTS[cls]
 
-_default_cache: Optional[BackendCache] = None
+
+_DEFAULTS: dict = {}
+
+
+def _default_device() -> int:
+    return int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+
+
+class BackendCache(ModelCache):
+    """task -> RestormerBackend."""
+    backend_name = 'RestormerBackend'
+    default_loader = staticmethod(default_state_dict_loader)
+
+    def get(self, task: str):
+        return self._get(task, lambda: task_config(task), lambda: self.loader(task, self.weight_dir))
 
 
 def default_cache() -> BackendCache:
-    global _default_cache
-    if _default_cache is None:
-        _default_cache = BackendCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
-    return _default_cache
+    return BackendCache.default()
 
 
 def set_default_cache(cache: Optional[BackendCache]):
-    global _default_cache
-    _default_cache = cache
+    _DEFAULTS[BackendCache] = cache
 
 
 # ------------------------------------------------------------------------------------------------
@@ -276,44 +293,20 @@ def default_swinir_loader(task: str, model_name: str, weight_dir: Optional[str] 
     return ckpt[key] if key in ckpt else ckpt
 
 
-class SwinIRCache:
-    """(task, checkpoint name) -> SwinIRBackend on one device, built on first use and kept for the life of the process."""
-
-    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
-                 backend_factory: Optional[Callable] = None):
-        self.device, self.weight_dir = device, weight_dir
-        self.loader = state_dict_loader or default_swinir_loader
-        self.factory = backend_factory
-        self.models: dict = {}
+class SwinIRCache(ModelCache):
+    """(task, checkpoint name) -> SwinIRBackend."""
+    backend_name = 'SwinIRBackend'
+    default_loader = staticmethod(default_swinir_loader)
 
     def get(self, task: str, model_name: str):
-        key = (task, model_name)
-        if key not in self.models:
+        def cfg():
             from .swinir import task_config as swinir_task_config
-            cfg = swinir_task_config(task, scale=4, large_model=True)          # multitask_tools.py:128-132: --scale 4 --large_model
-            sd = self.loader(task, model_name, self.weight_dir)
-            if self.factory is not None:
-                self.models[key] = self.factory(cfg, sd, self.device)
-            else:
-                from .backend import SwinIRBackend
-                self.models[key] = SwinIRBackend(cfg, sd, device=self.device)
-        return self.models[key]
-
-    def close(self):
-        for be in self.models.values():
-            if hasattr(be, 'close'):
-                be.close()
-        self.models.clear()
-
-
-_default_swinir_cache: Optional[SwinIRCache] = None
+            return swinir_task_config(task, scale=4, large_model=True)          # multitask_tools.py:128-132: --scale 4 --large_model
+        return self._get((task, model_name), cfg, lambda: self.loader(task, model_name, self.weight_dir))
 
 
 def default_swinir_cache() -> SwinIRCache:
-    global _default_swinir_cache
-    if _default_swinir_cache is None:
-        _default_swinir_cache = SwinIRCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
-    return _default_swinir_cache
+    return SwinIRCache.default()
 
 
 class SwinIR(Tool):
@@ -370,43 +363,20 @@ def default_xrestormer_loader(model_name: str, weight_dir: Optional[str] = None)
     return ckpt
 
 
-class XRestormerCache:
-    """checkpoint name -> XRestormerBackend on one device (every preset shares one architecture)."""
-
-    def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
-                 backend_factory: Optional[Callable] = None):
-        self.device, self.weight_dir = device, weight_dir
-        self.loader = state_dict_loader or default_xrestormer_loader
-        self.factory = backend_factory
-        self.models: dict = {}
+class XRestormerCache(ModelCache):
+    """checkpoint name -> XRestormerBackend (every preset shares one architecture)."""
+    backend_name = 'XRestormerBackend'
+    default_loader = staticmethod(default_xrestormer_loader)
 
     def get(self, model_name: str, scale: int = 1):
-        if model_name not in self.models:
+        def cfg():
             from .xrestormer import XRestormerConfig
-            cfg = XRestormerConfig(scale=scale)              # network_g of the configs: identical apart from scale
-            sd = self.loader(model_name, self.weight_dir)
-            if self.factory is not None:
-                self.models[model_name] = self.factory(cfg, sd, self.device)
-            else:
-                from .backend import XRestormerBackend
-                self.models[model_name] = XRestormerBackend(cfg, sd, device=self.device)
-        return self.models[model_name]
-
-    def close(self):
-        for be in self.models.values():
-            if hasattr(be, 'close'):
-                be.close()
-        self.models.clear()
-
-
-_default_xrestormer_cache: Optional[XRestormerCache] = None
+            return XRestormerConfig(scale=scale)              # network_g of the configs: identical apart from scale
+        return self._get(model_name, cfg, lambda: self.loader(model_name, self.weight_dir))
 
 
 def default_xrestormer_cache() -> XRestormerCache:
-    global _default_xrestormer_cache
-    if _default_xrestormer_cache is None:
-        _default_xrestormer_cache = XRestormerCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
-    return _default_xrestormer_cache
+    return XRestormerCache.default()
 
 
 class XRestormer(Tool):
@@ -485,43 +455,25 @@ def default_mprnet_loader(task: str, weight_dir: Optional[str] = None):
     return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
 
 
-class MPRNetCache:
-    """task ('Denoising' | 'Deblurring' | 'Deraining') -> MPRNetBackend on one device."""
+class MPRNetCache(ModelCache):
+    """task ('Denoising' | 'Deblurring' | 'Deraining') -> MPRNetBackend."""
+    backend_name = 'MPRNetBackend'
+    default_loader = staticmethod(default_mprnet_loader)
 
     def __init__(self, device: int = 0, state_dict_loader: Optional[Callable] = None, weight_dir: Optional[str] = None,
                  backend_factory: Optional[Callable] = None, config_fn: Optional[Callable] = None):
-        self.device, self.weight_dir = device, weight_dir
-        self.loader = state_dict_loader or default_mprnet_loader
-        self.factory, self.config_fn = backend_factory, config_fn
-        self.models: dict = {}
+        super().__init__(device, state_dict_loader, weight_dir, backend_factory)
+        self.config_fn = config_fn
 
     def get(self, task: str):
-        if task not in self.models:
-            from .mprnet import task_config
-            cfg = (self.config_fn or task_config)(task)
-            sd = self.loader(task, self.weight_dir)
-            if self.factory is not None:
-                self.models[task] = self.factory(cfg, sd, self.device)
-            else:
-                from .backend import MPRNetBackend
-                self.models[task] = MPRNetBackend(cfg, sd, device=self.device)
-        return self.models[task]
-
-    def close(self):
-        for be in self.models.values():
-            if hasattr(be, 'close'):
-                be.close()
-        self.models.clear()
-
-
-_default_mprnet_cache: Optional[MPRNetCache] = None
+        def cfg():
+            from .mprnet import task_config as mprnet_task_config
+            return (self.config_fn or mprnet_task_config)(task)
+        return self._get(task, cfg, lambda: self.loader(task, self.weight_dir))
 
 
 def default_mprnet_cache() -> MPRNetCache:
-    global _default_mprnet_cache
-    if _default_mprnet_cache is None:
-        _default_mprnet_cache = MPRNetCache(device=int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
-    return _default_mprnet_cache
+    return MPRNetCache.default()
 
 
 class MPRNet(Tool):
@@ -586,10 +538,6 @@ class HistogramEqualization(BrighteningTool):
 
     def __init__(self, device: int = 0):
         super().__init__(tool_name="histogram_equalization", device=device)
-
-
-def _default_device() -> int:
-    return int(os.environ.get('IRA_DEVICE', os.environ.get('LOCAL_RANK', '0')))
 
 
 def brightening_toolbox(device: int = 0) -> list:
