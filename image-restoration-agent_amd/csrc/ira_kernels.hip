@@ -155,106 +155,6 @@ __global__ __launch_bounds__(256) void k_pw_kres(const void* __restrict__ xin, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pointwise (1x1) conv, "N-resident": fp32 accumulators for all N output channels of the wave's pixels
-// stay in registers; the wave streams over K (one or two concatenated sources).  fp32 out with
-// optional residual add.  Used for attention apply (per-tile matrix M on V) + residual, project_out
-// + residual (restormer_arch.py:92,131,148-149), reduce_chan on cat([up, skip]) (:260-261,265-266).
-template <int NB, bool IN_F32, int PG>
-__global__ __launch_bounds__(256) void k_pw_nres(const void* __restrict__ x0, int K0,
-                                                 const void* __restrict__ x1, int K1,
-                                                 const f16* __restrict__ W, long w_tile_stride,
-                                                 const float* __restrict__ bias,
-                                                 const float* resid, float* y,   // may alias (x += ...)
-                                                 int N, int T, int P) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int chunks = (P + 32 * PG - 1) / (32 * PG);
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (long)T * chunks) return;
-    const int t = (int)(wv / chunks);
-    const int pbase = (int)(wv % chunks) * 32 * PG + r;
-    const int K = K0 + K1;
-    bool valid[PG];
-    long px[PG];
-#pragma unroll
-    for (int g = 0; g < PG; ++g) {
-        const int p = pbase + 32 * g;
-        valid[g] = p < P;
-        px[g] = (long)t * P + (valid[g] ? p : P - 1);
-    }
-
-    f32x16 acc[PG][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        f32x16 init = zero16();
-        if (bias != nullptr) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n = 32 * nb + 16 * u + 8 * h + j;
-                    init[8 * u + j] = (n < N) ? bias[n] : 0.f;
-                }
-        }
-#pragma unroll
-        for (int g = 0; g < PG; ++g) acc[g][nb] = init;
-    }
-
-    // W: fragment-major [2][NB][KT][64][8] per matrix (hi plane, lo plane); w_tile_stride counts both planes
-    const int KT = K >> 4;
-    const f16* wrow = W + (long)t * w_tile_stride + lane * 8;
-    const long lo_off = (long)NB * KT * 512;
-    for (int s = 0; s < KT; ++s) {
-        const int c0 = 16 * s;
-        half8 b[PG];
-#pragma unroll
-        for (int g = 0; g < PG; ++g) {
-            if constexpr (IN_F32) {
-                const float* src = (c0 < K0) ? ((const float*)x0 + px[g] * K0 + c0 + 8 * h)
-                                             : ((const float*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
-                b[g] = cvt8(*(const f32x4*)src, *(const f32x4*)(src + 4));
-            } else {
-                const f16* src = (c0 < K0) ? ((const f16*)x0 + px[g] * K0 + c0 + 8 * h)
-                                           : ((const f16*)x1 + px[g] * K1 + (c0 - K0) + 8 * h);
-                b[g] = *(const half8*)src;
-            }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const half8 a = *(const half8*)(wrow + ((long)nb * KT + s) * 512);
-            const half8 al = *(const half8*)(wrow + lo_off + ((long)nb * KT + s) * 512);
-#pragma unroll
-            for (int g = 0; g < PG; ++g) {
-                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[g], acc[g][nb], 0, 0, 0);
-                acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g], acc[g][nb], 0, 0, 0);
-            }
-        }
-    }
-
-#pragma unroll
-    for (int g = 0; g < PG; ++g) {
-        if (!valid[g]) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n0 = 32 * nb + 16 * u + 8 * h;
-                if (n0 + 8 <= N) {
-                    f32x4 lo, hi;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { lo[j] = acc[g][nb][8 * u + j]; hi[j] = acc[g][nb][8 * u + 4 + j]; }
-                    if (resid != nullptr) {
-                        const f32x4 rl = *(const f32x4*)(resid + px[g] * N + n0);
-                        const f32x4 rh = *(const f32x4*)(resid + px[g] * N + n0 + 4);
-                        lo += rl; hi += rh;
-                    }
-                    *(f32x4*)(y + px[g] * N + n0) = lo;
-                    *(f32x4*)(y + px[g] * N + n0 + 4) = hi;
-                }
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // LDS-shared-weight variants for the wide levels (C = 192 / 384).  There a weight block is 24-48 KB and each
 // wave of k_pw_kres / k_pw_nres streamed the whole matrix (up to 3 MB) from L2 for its 32 pixels: the kernels were
 // L2-bandwidth bound at ~0.5 TB/s of useful traffic.  Here the 4 waves of a workgroup stage every weight block in
@@ -1740,17 +1640,6 @@ hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mod
     }
 }
 
-template <int NB, int PG>
-static hipError_t pw_nres_launch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
-                                 const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
-                                 int T, int P) {
-    const long waves = (long)T * ((P + 32 * PG - 1) / (32 * PG));
-    const dim3 grid(grid1d(waves, 4)), block(256);
-    if (in_f32) hipLaunchKernelGGL((k_pw_nres<NB, true, PG>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    else hipLaunchKernelGGL((k_pw_nres<NB, false, PG>), grid, block, 0, st, x0, K0, x1, K1, W, wts, bias, resid, y, N, T, P);
-    return hipGetLastError();
-}
-
 template <int NBW, int PG>
 static hipError_t pw_nres_lds_launch_w(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                        const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
@@ -1783,14 +1672,9 @@ template <int NB>
 static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                                    const f16* W, long wts, const float* bias, const float* resid, float* y, int N,
                                    int T, int P) {
-    static const int lds_env = env_int("IRA_PW_LDS", 2);
-    if (lds_env >= 2 || (NB >= 6 && lds_env)) return pw_nres_lds_launch<NB>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P);
-    static const int pg_env = env_int("IRA_NRES_PG", 0);
-    int pg = pg_env > 0 ? pg_env : (NB <= 4 ? 2 : 1);
-    while (pg > 1 && P <= 32 * (pg / 2)) pg /= 2;
-    if constexpr (NB <= 3) { if (pg >= 4) return pw_nres_launch<NB, 4>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
-    if constexpr (NB <= 6) { if (pg >= 2) return pw_nres_launch<NB, 2>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P); }
-    return pw_nres_launch<NB, 1>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P);
+    // weights of every shape through LDS (the per-wave streaming kernel k_pw_nres of round 1 is retired: k_pw_nres_lds superseded it on every
+    // shape, and single-input calls go to k_pw_gemm / k_nres_wide before they get here)
+    return pw_nres_lds_launch<NB>(st, x0, K0, x1, K1, in_f32, W, wts, bias, resid, y, N, T, P);
 }
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32, const void* W,
