@@ -85,6 +85,7 @@ hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const f
 
 hipError_t launch_sum_records(hipStream_t st, const float* part, int S, int reclen, float* out);   // out[i] = sum_s part[s][i]
 hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx);
+hipError_t launch_copy_slice(hipStream_t st, const float* b, int Cb, float* out, int ldo, int off, long npx);
 
 // tiler
 hipError_t launch_extract_tiles(hipStream_t st, const uint8_t* frame, int h, int w, int c, int Hp, int Wp,

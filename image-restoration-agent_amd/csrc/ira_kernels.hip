@@ -987,7 +987,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
                 } else if constexpr (MODE == 2) {
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
-                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * ldout + cc] = val;      // MODE 2: ldout = floats per OUTPUT pixel (>= N / 4)
                 } else {
                     const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_lds(const float* __restrict__ i
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
                 } else if constexpr (MODE == 2) {
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
-                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * ldout + cc] = val;      // MODE 2: ldout = floats per OUTPUT pixel (>= N / 4)
                 } else {
                     const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                 const int yo = yo0 + (op >> 5), xo = xo0 + (op & 31);
                 const float* sp = stg + op * PS + 4 * piece;
                 f32x4 v4; v4[0] = sp[0]; v4[1] = sp[1]; v4[2] = sp[2]; v4[3] = sp[3];
-                if (yo < 2 * H && xo < 2 * Wd && cc0 + 4 <= N4) *(f32x4*)(out + (((long)t * (2 * H) + yo) * (2 * Wd) + xo) * N4 + cc0) = v4;
+                if (yo < 2 * H && xo < 2 * Wd && cc0 + 4 <= N4) *(f32x4*)(out + (((long)t * (2 * H) + yo) * (2 * Wd) + xo) * ldout + cc0) = v4;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_tile(const float* __restrict__ 
                     out[(((long)t * (H >> 1) + (y >> 1)) * (Wd >> 1) + (x >> 1)) * (4 * N) + oc] = val;
                 } else if constexpr (MODE == 2) {
                     const int cc = n >> 2, sy = (n >> 1) & 1, sx = n & 1;
-                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * (N >> 2) + cc] = val;
+                    out[(((long)t * (2 * H) + 2 * y + sy) * (2 * Wd) + 2 * x + sx) * ldout + cc] = val;      // MODE 2: ldout = floats per OUTPUT pixel (>= N / 4)
                 } else {
                     const long o = ((long)t * P + p) * ldout + n;
                     out[o] = val + skip[o];
@@ -1417,6 +1417,17 @@ __global__ __launch_bounds__(256) void k_concat2(const float* __restrict__ a, in
         const int cv = (int)(idx % Cv) * 4;
         const f32x4 v = (cv < Ca) ? *(const f32x4*)(a + px * Ca + cv) : *(const f32x4*)(b + px * Cb + (cv - Ca));
         *(f32x4*)(out + px * (Ca + Cb) + cv) = v;
+    }
+}
+
+// out[px][off .. off + Cb) = b[px][0 .. Cb): the skip half of torch.cat when the other half was written in place by its producer
+__global__ __launch_bounds__(256) void k_copy_slice(const float* __restrict__ b, int Cb, float* __restrict__ out, int ldo, int off, long npx) {
+    const int Cv = Cb >> 2;
+    const long total = npx * Cv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long px = idx / Cv;
+        const int cv = (int)(idx % Cv) * 4;
+        *(f32x4*)(out + px * ldo + off + cv) = *(const f32x4*)(b + px * Cb + cv);
     }
 }
 
@@ -1857,8 +1868,10 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const 
     // ldin / ldout: floats per pixel of the input / of the output and skip tensors (0 = K / N): a convolution can read the first K
     // channels of a wider pixel and write N channels into a slice of one (dense blocks, RRDBNet); float4 loads need ldin % 4 == 0
     if (ldin == 0) ldin = K;
-    if (ldout == 0) ldout = N;
-    if (ldin < K || (ldin & 3) || ldout < N || ((mode == 1 || mode == 2) && ldout != N)) return hipErrorInvalidValue;
+    // mode 2 (PixelShuffle): ldout counts floats per OUTPUT pixel (default N / 4), so that the shuffled result can land in the first
+    // N / 4 channels of a wider pixel (the level-1 concat buffer of the decoder: no separate copy of the up-sampled half)
+    if (ldout == 0) ldout = (mode == 2) ? N / 4 : N;
+    if (ldin < K || (ldin & 3) || (mode == 2 ? (ldout < N / 4 || (ldout & 3)) : ldout < N) || (mode == 1 && ldout != N)) return hipErrorInvalidValue;
     if (mode == 1 && ((H | Wd) & 1)) return hipErrorInvalidValue;
     if (mode == 2 && (N & 3)) return hipErrorInvalidValue;
     if (mode == 3 && skip == nullptr) return hipErrorInvalidValue;
@@ -1884,6 +1897,12 @@ hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const f
 hipError_t launch_concat2(hipStream_t st, const float* a, int Ca, const float* b, int Cb, float* out, long npx) {
     if ((Ca | Cb) & 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_concat2, dim3(grid1d(npx * ((Ca + Cb) / 4), 256, 65536)), dim3(256), 0, st, a, Ca, b, Cb, out, npx);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_slice(hipStream_t st, const float* b, int Cb, float* out, int ldo, int off, long npx) {
+    if ((Cb | ldo | off) & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_copy_slice, dim3(grid1d(npx * (Cb / 4), 256, 65536)), dim3(256), 0, st, b, Cb, out, ldo, off, npx);
     return hipGetLastError();
 }
 

@@ -369,8 +369,10 @@ int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W
     RUN(m, "reduce_1x1", ira::launch_pw_nres(st, m->u2, g.C[1], e2, g.C[1], true, m->red2, 0, m->red2_b, nullptr, d2, g.C[1], nb(g.C[1]), T, (int)g.P[1]));
     if ((rc = run_stage(m, m->dec2, d2, m->ad2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1], 1))) return rc;
     if ((rc = strip_halo(m, d2, g.H[1], g.W[1], g.C[1], 1))) return rc;
-    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, m->u1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2)));
-    RUN(m, "concat", ira::launch_concat2(st, m->u1, g.C[0], e1, g.C[0], d1, (long)T * g.P[0]));                                        // :270
+    // torch.cat([up2_1(d2), e1], 1) (:269-270): the up-convolution's PixelShuffle epilogue writes its half straight into the first C
+    // channels of the 2C-wide buffer, only the skip half is copied
+    RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, d1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2), 0.f, 0, 2 * g.C[0]));
+    RUN(m, "concat", ira::launch_copy_slice(st, e1, g.C[0], d1, 2 * g.C[0], g.C[0], (long)T * g.P[0]));
     float* a1 = m->ad1;
     if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1], 0))) return rc;                              // :271
     a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
