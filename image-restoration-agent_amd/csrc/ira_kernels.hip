@@ -1373,8 +1373,9 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, con
     __syncthreads();
     const int G = C >> 3;
     const long total = (long)T * H * W * G;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    // a workgroup stages the weights once and then walks `gridDim.x`-strided over 256-item slices (one slice per workgroup meant 5 KB of
+    // weights fetched, written to LDS and a barrier for every 42 pixels)
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int g = (int)(idx % G);
     const long px = idx / G;
     const int x = (int)(px % W);
@@ -1406,6 +1407,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ in, con
     float* dst = out + px * C + g * 8;
     *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
     *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
 }
 
 __global__ __launch_bounds__(256) void k_concat2(const float* __restrict__ a, int Ca, const float* __restrict__ b,
@@ -1890,7 +1892,7 @@ hipError_t launch_embed(hipStream_t st, const float* in, const float* w, const f
                         int W, int ic, int C, int relu) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)T * H * W * (C / 8);
-    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256)), dim3(256), (size_t)C * ic * 9 * sizeof(float), st, in, w, bias, out, T, H, W, ic, C, relu);
+    hipLaunchKernelGGL(k_embed, dim3(grid1d(total, 256, 256L * 16)), dim3(256), (size_t)C * ic * 9 * sizeof(float), st, in, w, bias, out, T, H, W, ic, C, relu);
     return hipGetLastError();
 }
 

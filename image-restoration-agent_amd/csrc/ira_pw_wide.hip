@@ -12,6 +12,8 @@
 //     registers, and no vector-memory result is consumed inside the loop (the old kernel's accumulator init from `bias` made the compiler wait
 //     vmcnt(0) - i.e. for the just-issued weight prefetch - in front of the first MFMA of every iteration).  A phase stagger of the first
 //     workgroup on each CU (tried: 0 / 8k / 16k / 32k cycles per class) changes nothing: the kernel is not HBM-burst-bound in its prologue.
+//     Nor is the prologue bound by its fragment-shaped loads (32 cache lines per instruction): a variant that copied each group's pixel rows
+//     with fully contiguous loads through wave-private LDS rows and picked the fragments out of LDS measured the same (0.73-0.75 vs 0.72 ms).
 // Numerics are those of k_pw_kres_lds: same LayerNorm arithmetic, same fragment order of the hi and lo MFMAs per accumulator.
 #include "ira_kernels.h"
 #include "ira_device.h"
