@@ -149,12 +149,16 @@ int env_int_n(const char* name, int dflt) {
 
 bool nres_wide_supported(int K, int N, int NB, int T, int P, long w_tile_stride) {
     static const int on = env_int_n("IRA_NRES_WIDE", 1);
-    return on && K >= 128 && K % 64 == 0 && (NB == 6 || NB == 12) && N % 4 == 0 && N > 32 * (NB - 1) && (long)T * P >= 32768 && T > 0 && P > 0;
+    if (!on || N % 4 != 0 || N <= 32 * (NB - 1) || (long)T * P < 32768 || T <= 0 || P <= 0 || K < 128) return false;
+    if (NB == 6 || NB == 12) return K % 64 == 0;          // Restormer / X-Restormer levels 3-4: six row blocks, stages of four k-steps
+    if (NB == 8) return K % 64 == 0 || K % 48 == 0;        // SwinIR-L proj / fc2 (N = 256 padded, K = 256 / 480): eight row blocks, stages of four / three k-steps
+    return false;
 }
 
-hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
-                            int N, int NB, int T, int P) {
-    constexpr int NBW = 6, NW = 8, KSI = 4;
+template <int NBW, int KSI>
+static hipError_t nres_wide_launch(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid,
+                                   float* y, int N, int NB, int T, int P) {
+    constexpr int NW = 8;
     const dim3 grid((unsigned)((long)T * ((P + 32 * NW - 1) / (32 * NW))), (unsigned)(NB / NBW)), block(64 * NW);
     const size_t smem = (size_t)2 * KSI * NBW * 2 * 1024;
     static std::atomic<uint64_t> done_b{0}, done_n{0};
@@ -166,6 +170,15 @@ hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W,
         hipLaunchKernelGGL((k_nres_wide<NBW, NW, KSI, false>), grid, block, smem, st, (const f16*)x, K, (const f16*)W, w_tile_stride, bias, resid, y, N, NB, T, P);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
+                            int N, int NB, int T, int P) {
+    if (NB == 8) {
+        if (K % 64 == 0) return nres_wide_launch<8, 4>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        return nres_wide_launch<8, 3>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+    }
+    return nres_wide_launch<6, 4>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
 }
 
 }  // namespace ira

@@ -236,6 +236,8 @@ hipError_t pw_wide_launch(hipStream_t st, const void* x, bool in_f32, int ln, co
 
 bool pw_wide_supported(int K, long npx) {
     static const int on = env_int_w("IRA_PW_WIDE", 1);
+    // K = 256 (SwinIR-L, 240 channels padded) was tried with one row block per iteration (two need 2 x 64 KB of weight stages): LN + qkv
+    // 31.3 -> 31.2 ms per frame, LN + fc1 25.8 -> 27.9: not dispatched
     return on && ((K == 192 && npx >= 512L * 64) || (K == 384 && npx >= 256L * 64));
 }
 
@@ -243,13 +245,11 @@ hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mod
                           int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
     if (ln_n <= 0 || ln_n > K) ln_n = K;
     if (n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
-    static const int cfg = env_int_w("IRA_PW_WIDE_CFG", 0);
-    if (K == 192) {
-        if (cfg == 1) return pw_wide_launch<12, 8, 2, 1, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act);
-        if (cfg == 3) return pw_wide_launch<12, 4, 2, 1, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act);
-        return pw_wide_launch<12, 8, 2, 2, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act);
-    }
-    if (K == 384) return pw_wide_launch<24, 8, 1, 1, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act);
+#define IRA_PWW(KS_, NW_, PG_, NBI_) \
+    return pw_wide_launch<KS_, NW_, PG_, NBI_, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act)
+    if (K == 192) IRA_PWW(12, 8, 2, 2);
+    if (K == 384) IRA_PWW(24, 8, 1, 1);
+#undef IRA_PWW
     return hipErrorInvalidValue;
 }
 

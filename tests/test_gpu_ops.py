@@ -121,6 +121,8 @@ def test_pw_kres(ctx, K, N, ln, in_f32, T, P, with_bias):
     (192, 0, False, 192, 3, 11000, True, True, False),   # k_nres_wide: attention apply, one matrix per tile, tiles that are no multiple of 256 px
     (1024, 0, False, 384, 1, 33000, True, False, True),  # k_nres_wide: N = 384 as two halves, bias, 16 stages
     (256, 0, False, 184, 1, 32800, False, False, False), # k_nres_wide: N not a multiple of 32 (partial last row block), no residual
+    (480, 0, False, 240, 1, 33001, True, False, True),   # k_nres_wide with eight row blocks, stages of three k-steps (SwinIR-L fc2), ragged
+    (256, 0, False, 256, 2, 16384, True, False, True),   # eight row blocks, stages of four (SwinIR-L proj)
 ])
 def test_pw_nres(ctx, K0, K1, in_f32, N, T, P, resid, per_tile, with_bias):
     g = torch.Generator().manual_seed(K0 + 3 * N + K1)

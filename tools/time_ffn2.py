@@ -11,7 +11,7 @@ from ira_amd.weights import seeded_state_dict
 from ira_amd.pack import pack_block, frag_major, split16
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 96
-hid = int(Cc * 2.66)
+hid = int(os.environ.get("FFN_HID", int(Cc * 2.66)))
 H = W = 512
 cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1))
 Hp = (hid + 31) // 32 * 32
