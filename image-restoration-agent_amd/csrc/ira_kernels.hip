@@ -236,20 +236,28 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_pw_kres_lds(const void* __res
     for (int i = 0; i < SH; ++i) if (wave + NW * i < F) wl[(wave + NW * i) * 64 + lane] = stg[i];
     __syncthreads();
 
+    f32x16 binit = zero16();
+    if (bias != nullptr) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) binit[8 * u + j] = bias[32 * nb_lo + 16 * u + 8 * h + j];
+    }
     for (int nb = nb_lo; nb < nb_hi; ++nb) {
         const half8* cur = wl + ((nb - nb_lo) & 1) * F * 64;
+        // The accumulators start from the bias of THIS block, fetched one iteration ago together with the weight prefetch.  Loaded here
+        // instead, the wait for the bias in front of the first MFMA was vmcnt(0) (vector-memory results return in order): every iteration
+        // of every layer with a bias (SwinIR, X-Restormer, WithBias Restormer) waited for the weights of the NEXT block - an L2 round trip.
+        f32x16 acc = binit;
         if (nb + 1 < nb_hi) {
 #pragma unroll
             for (int i = 0; i < SH; ++i) if (wave + NW * i < F) stg[i] = *gsrc(nb + 1, wave + NW * i);     // prefetch, issued before the stores below
-        }
-        f32x16 acc;
-        if (bias != nullptr) {
+            if (bias != nullptr) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[8 * u + j] = bias[32 * nb + 16 * u + 8 * h + j];
-        } else {
-            acc = zero16();
+                    for (int j = 0; j < 8; ++j) binit[8 * u + j] = bias[32 * (nb + 1) + 16 * u + 8 * h + j];
+            }
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
