@@ -326,7 +326,9 @@ def main_swinir(args):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * step_s, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 storage / f32 accumulate + f32 token stream', 'data': 'synthetic',
         'config': {'workload': f'SwinIR-L x4 (28.0M params, seeded weights), {w}x{h} uint8 frame -> {w * s}x{h * s}, padded to {Wp}x{Hp}, whole image, '
-                               f'one frame per GPU per step', 'frames_per_s': round(world / step_s, 3), 'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
+                               f'one frame per GPU per step; transformer 1x1 layers on the fp16 hi weight plane (SwinIRBackend default, '
+                               f'ira_set_weight_planes(1): |dPSNR| 6e-5 dB at this geometry, tests/test_gpu_benchgeom.py)',
+                   'frames_per_s': round(world / step_s, 3), 'device_ms_per_step_rank0': round(dev_ms / args.steps, 3)},
         'net_roofline': {'bound': 'mfma (SURVEY 8d: 467 FLOP/B under the fusion contract)', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
                          'hbm_achieved_GBs': round(net_bytes / 1e9 / step_s, 1), 'hbm_frac': round(net_bytes / 1e9 / step_s / HBM_PEAK_GBS, 4),
                          'algorithmic_TFLOP_per_step': round(flops / 1e12, 2), 'mfma_achieved_TFLOPs': round(flops / 1e12 / step_s, 1),

@@ -25,11 +25,12 @@ inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<u
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K,
                           const void* W, const float* bias, void* y, int y_stride, int n_store,
-                          int NB, int T, int P, float eps = 1e-5f, int ln_n = 0, int act = 0);   // ln_n: true channel count when K is zero-padded; act 1 = GELU
+                          int NB, int T, int P, float eps = 1e-5f, int ln_n = 0, int act = 0, int planes = 2);   // ln_n: true channel count when K is zero-padded; act 1 = GELU;
+                          // planes 1 = use the fp16 hi plane of W alone where a kernel for that exists (ira_set_weight_planes), else both
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32,
                           const void* W, long w_tile_stride, const float* bias, const float* resid,
-                          float* y, int N, int NB, int T, int P);
+                          float* y, int N, int NB, int T, int P, int planes = 2);
 
 hipError_t launch_dwconv_qkv(hipStream_t st, const void* in, const float* w, const float* bias,
                              void* qk, void* v, int T, int H, int W, int C);
@@ -57,14 +58,14 @@ hipError_t launch_ffn_fused(hipStream_t st, const float* x, float* x_out, int ln
 // Fused attention apply + GDFN, second generation (ira_ffn2.hip): x_out = x1 + ffn(LN(x1)), x1 = x + M_t . v (+ wo_b); v == M == nullptr: x1 = x.
 // M: the per-tile matrices of launch_attn_mix (fp16 hi + lo planes, fragment-major), m_tile_stride in halfs.
 // ira_pw_wide.hip: LayerNorm + 1x1 for K = 192 with 512-pixel workgroups (arguments of launch_pw_kres)
-bool pw_wide_supported(int K, long npx);
+bool pw_wide_supported(int K, long npx, int planes = 2);
 hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W, const float* bias, void* y, int y_stride,
-                          int n_store, int NB, int T, int P, float eps, int ln_n, int act);
+                          int n_store, int NB, int T, int P, float eps, int ln_n, int act, int planes = 2);
 
 // ira_nres_wide.hip: 1x1 + residual for N = 192 / 384 (fp16 pixels, one input tensor) in 256-pixel workgroups
 bool nres_wide_supported(int K, int N, int NB, int T, int P, long w_tile_stride);
 hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
-                            int N, int NB, int T, int P);
+                            int N, int NB, int T, int P, int planes = 2);
 
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);

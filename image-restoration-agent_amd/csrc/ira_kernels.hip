@@ -1648,9 +1648,10 @@ static hipError_t pw_kres_dispatch(hipStream_t st, const void* x, bool in_f32, i
 }
 
 hipError_t launch_pw_kres(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W,
-                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
+                          const float* bias, void* y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act, int planes) {
     if (ln_n <= 0 || ln_n > K) ln_n = K;          // 0 = "all K channels are real"
     if (K % 16 != 0 || n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
+    if (planes == 1 && pw_wide_supported(K, (long)T * P, 1)) return launch_pw_wide(st, x, in_f32, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act, 1);
     if (pw_wide_supported(K, (long)T * P)) return launch_pw_wide(st, x, in_f32, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act);
     const f16* Wh = (const f16*)W; f16* yh = (f16*)y;
     switch (K / 16) {
@@ -1700,10 +1701,10 @@ static hipError_t pw_nres_dispatch(hipStream_t st, const void* x0, int K0, const
 
 hipError_t launch_pw_nres(hipStream_t st, const void* x0, int K0, const void* x1, int K1, bool in_f32, const void* W,
                           long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T,
-                          int P) {
+                          int P, int planes) {
     if (K0 % 16 != 0 || K1 % 16 != 0 || N % 8 != 0 || NB * 32 < N) return hipErrorInvalidValue;
     if ((x1 == nullptr || K1 == 0) && !in_f32 && nres_wide_supported(K0, N, NB, T, P, w_tile_stride))
-        return launch_nres_wide(st, x0, K0, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        return launch_nres_wide(st, x0, K0, W, w_tile_stride, bias, resid, y, N, NB, T, P, planes == 1 ? 1 : 2);
     if ((x1 == nullptr || K1 == 0) && pw_gemm_supported(K0, N, NB))      // one input tensor: both operands through LDS (ira_nafnet.hip)
         return launch_pw_gemm(st, x0, in_f32, K0, W, w_tile_stride, bias, resid, y, N, NB, T, P);
     const f16* Wh = (const f16*)W;

@@ -119,7 +119,8 @@ struct ira_model {
     float *xe1, *xe2, *xe3, *x4, *xd3, *xd2, *xd1, *u3, *u2, *u1, *part, *attnA;
     float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
     bool use_fused_ffn = true;
-    int ffn_gen = 2;                  // 2: ira_ffn2.hip (attention apply folded in); 1: ira_ffn_fused.hip + separate apply (IRA_FFN_GEN=1)
+    int ffn_gen = 2;
+    int w_planes = 2;          // ira_set_weight_planes: 1 = the 1x1 layers of this model use the hi plane alone where a kernel for that exists                  // 2: ira_ffn2.hip (attention apply folded in); 1: ira_ffn_fused.hip + separate apply (IRA_FFN_GEN=1)
     // strip-parallel whole-frame forward (ira_strip_*): this rank's band of rows with halo rows of its neighbours
     bool strip_set = false, strip_on = false;
     ira_strip_comm scomm{};

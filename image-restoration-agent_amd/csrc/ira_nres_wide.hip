@@ -22,15 +22,16 @@ namespace ira {
 
 namespace {
 
-template <int NBW, int NW, int KSI, bool HAS_BIAS>
+template <int NBW, int NW, int KSI, bool HAS_BIAS, bool LO>
 __global__ __launch_bounds__(64 * NW, 2) void k_nres_wide(const f16* __restrict__ x, int K, const f16* __restrict__ W, long w_tile_stride,
                                                           const float* __restrict__ bias, const float* resid, float* y, int N, int NBtot, int T,
                                                           int P) {
     static_assert(NBW % 2 == 0, "the epilogue moves two row blocks at a time");
-    constexpr int FS = KSI * NBW * 2;            // 1 KB fragments per stage: [k-step][plane][row block]
+    constexpr int NPL = LO ? 2 : 1;              // weight planes used: hi + lo, or (ira_set_weight_planes(1)) the fp16 hi plane alone
+    constexpr int FS = KSI * NBW * NPL;          // 1 KB fragments per stage: [k-step][plane][row block]
     constexpr int WBUF = FS * 1024;
     constexpr int RS = 64 * 4 + 16;              // transposition row stride in bytes: 64 floats + pad
-    static_assert(NW * 32 * RS <= 2 * WBUF, "the transposition rows must fit the weight buffers");
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_nres_wide(const f16* __restrict_
         for (int i = 0; i < (FS + NW - 1) / NW; ++i) {
             const int f = wave + NW * i;
             if (f < FS) {
-                const int ks = f / (2 * NBW), rem = f - ks * 2 * NBW, plane = rem / NBW, nb = rem - plane * NBW;
+                const int ks = f / (NPL * NBW), rem = f - ks * NPL * NBW, plane = rem / NBW, nb = rem - plane * NBW;
                 const int blk = min(nb0 + nb, NBtot - 1);
                 const long off = (plane ? lo_off : 0) + ((long)blk * KT + sti * KSI + ks) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wlane + off),
@@ -90,9 +91,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_nres_wide(const f16* __restrict_
         for (int ks = 0; ks < KSI; ++ks)
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
-                const half8 ah = cur[(ks * 2 * NBW + nb) * 64 + lane], al = cur[(ks * 2 * NBW + NBW + nb) * 64 + lane];
+                const half8 ah = cur[(ks * NPL * NBW + nb) * 64 + lane];
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[set][ks], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[set][ks], acc[nb], 0, 0, 0);
+                if constexpr (LO) {
+                    const half8 al = cur[(ks * NPL * NBW + NBW + nb) * 64 + lane];
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[set][ks], acc[nb], 0, 0, 0);
+                }
             }
         // no store is issued in this loop: everything outstanding on the vector-memory counter is the next stage (DMA + pixel fragments)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -155,30 +159,36 @@ bool nres_wide_supported(int K, int N, int NB, int T, int P, long w_tile_stride)
     return false;
 }
 
-template <int NBW, int KSI>
+template <int NBW, int KSI, bool LO>
 static hipError_t nres_wide_launch(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid,
                                    float* y, int N, int NB, int T, int P) {
     constexpr int NW = 8;
     const dim3 grid((unsigned)((long)T * ((P + 32 * NW - 1) / (32 * NW))), (unsigned)(NB / NBW)), block(64 * NW);
-    const size_t smem = (size_t)2 * KSI * NBW * 2 * 1024;
+    // two weight stages, and at least the epilogue's transposition rows (8 waves x 32 x 272 B), which reuse the same LDS
+    const size_t smem = std::max((size_t)2 * KSI * NBW * (LO ? 2 : 1) * 1024, (size_t)NW * 32 * (64 * 4 + 16));
     static std::atomic<uint64_t> done_b{0}, done_n{0};
     if (bias != nullptr) {
-        if (hipError_t e = ensure_dynamic_lds((const void*)k_nres_wide<NBW, NW, KSI, true>, smem, done_b); e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_nres_wide<NBW, NW, KSI, true>), grid, block, smem, st, (const f16*)x, K, (const f16*)W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        if (hipError_t e = ensure_dynamic_lds((const void*)k_nres_wide<NBW, NW, KSI, true, LO>, smem, done_b); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_nres_wide<NBW, NW, KSI, true, LO>), grid, block, smem, st, (const f16*)x, K, (const f16*)W, w_tile_stride, bias, resid, y, N, NB, T, P);
     } else {
-        if (hipError_t e = ensure_dynamic_lds((const void*)k_nres_wide<NBW, NW, KSI, false>, smem, done_n); e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_nres_wide<NBW, NW, KSI, false>), grid, block, smem, st, (const f16*)x, K, (const f16*)W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        if (hipError_t e = ensure_dynamic_lds((const void*)k_nres_wide<NBW, NW, KSI, false, LO>, smem, done_n); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_nres_wide<NBW, NW, KSI, false, LO>), grid, block, smem, st, (const f16*)x, K, (const f16*)W, w_tile_stride, bias, resid, y, N, NB, T, P);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
-                            int N, int NB, int T, int P) {
+                            int N, int NB, int T, int P, int planes) {
     if (NB == 8) {
-        if (K % 64 == 0) return nres_wide_launch<8, 4>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
-        return nres_wide_launch<8, 3>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        if (planes == 1) {
+            if (K % 64 == 0) return nres_wide_launch<8, 4, false>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+            return nres_wide_launch<8, 3, false>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        }
+        if (K % 64 == 0) return nres_wide_launch<8, 4, true>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+        return nres_wide_launch<8, 3, true>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
     }
-    return nres_wide_launch<6, 4>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+    if (planes == 1) return nres_wide_launch<6, 4, false>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
+    return nres_wide_launch<6, 4, true>(st, x, K, W, w_tile_stride, bias, resid, y, N, NB, T, P);
 }
 
 }  // namespace ira

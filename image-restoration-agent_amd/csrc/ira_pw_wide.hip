@@ -26,12 +26,13 @@ namespace ira {
 
 namespace {
 
-template <int KS, int LN, bool IN_F32, bool HAS_BIAS, int NW, int PG, int NBI, int MINW>
+template <int KS, int LN, bool IN_F32, bool HAS_BIAS, int NW, int PG, int NBI, int MINW, bool LO>
 __global__ __launch_bounds__(64 * NW, MINW) void k_pw_wide(const void* __restrict__ xin, const f16* __restrict__ W, const float* __restrict__ bias,
                                                            f16* __restrict__ y, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n,
                                                            int act) {
     constexpr int K = KS * 16;
-    constexpr int F = 2 * KS;                    // 1 KB fragments per 32-row block: hi plane k-steps, then lo plane k-steps
+    constexpr int F = (LO ? 2 : 1) * KS;         // 1 KB fragments per 32-row block: hi plane k-steps, then (LO) lo plane k-steps; !LO: the layer runs on
+                                                 // fp16 weights (the hi plane alone), for nets whose goldens allow it (ira_set_weight_planes)
     constexpr int FI = NBI * F;                  // fragments per iteration
     constexpr int SH = (FI + NW - 1) / NW;       // fragments each wave stages per iteration
     constexpr int RS = NBI * 64 + 16;            // transposition row stride in bytes (one pixel: NBI x 32 fp16 + pad)
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_pw_wide(const void* __restric
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int j = 0; j < NBI; ++j) {
-                const half8 ah = cur[(j * F + s) * 64 + lane], al = cur[(j * F + KS + s) * 64 + lane];
+                const half8 ah = cur[(j * F + s) * 64 + lane];
 #pragma unroll
-                for (int g = 0; g < PG; ++g) {
-                    acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[g][s], acc[g][j], 0, 0, 0);
-                    acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g][s], acc[g][j], 0, 0, 0);
+                for (int g = 0; g < PG; ++g) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[g][s], acc[g][j], 0, 0, 0);
+                if constexpr (LO) {
+                    const half8 al = cur[(j * F + KS + s) * 64 + lane];
+#pragma unroll
+                    for (int g = 0; g < PG; ++g) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[g][s], acc[g][j], 0, 0, 0);
                 }
             }
         }
@@ -205,7 +208,7 @@ int env_int_w(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-template <int KS, int NW, int PG, int NBI, int MINW>
+template <int KS, int NW, int PG, int NBI, int MINW, bool LO>
 hipError_t pw_wide_launch(hipStream_t st, const void* x, bool in_f32, int ln, const f16* W, const float* bias, f16* y, int ys, int ns, int NB,
                           int T, int P, float eps, int ln_n, int act) {
     const long groups = (long)T * ((P + 31) / 32);
@@ -213,12 +216,12 @@ hipError_t pw_wide_launch(hipStream_t st, const void* x, bool in_f32, int ln, co
     int splits = 1;
     if (wgs < 256 && NB >= 8) splits = (int)std::min<long>(NB / (2 * NBI), (512 + wgs - 1) / wgs);
     const dim3 grid((unsigned)wgs, std::max(splits, 1)), block(64 * NW);
-    const size_t smem = (size_t)2 * (NBI * 2 * KS * 1024 + 256) + (size_t)NW * 32 * (NBI * 64 + 16);
+    const size_t smem = (size_t)2 * (NBI * (LO ? 2 : 1) * KS * 1024 + 256) + (size_t)NW * 32 * (NBI * 64 + 16);
 #define IRA_KW2(LN_, F32_, B_)                                                                                                                          \
     do {                                                                                                                                                \
         static std::atomic<uint64_t> done_{0};                                                                                                          \
-        if (hipError_t e_ = ensure_dynamic_lds((const void*)k_pw_wide<KS, LN_, F32_, B_, NW, PG, NBI, MINW>, smem, done_); e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL((k_pw_wide<KS, LN_, F32_, B_, NW, PG, NBI, MINW>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);   \
+        if (hipError_t e_ = ensure_dynamic_lds((const void*)k_pw_wide<KS, LN_, F32_, B_, NW, PG, NBI, MINW, LO>, smem, done_); e_ != hipSuccess) return e_; \
+        hipLaunchKernelGGL((k_pw_wide<KS, LN_, F32_, B_, NW, PG, NBI, MINW, LO>), grid, block, smem, st, x, W, bias, y, ys, ns, NB, T, P, eps, ln_n, act);   \
     } while (0)
 #define IRA_KW(LN_, F32_) do { if (bias != nullptr) IRA_KW2(LN_, F32_, true); else IRA_KW2(LN_, F32_, false); } while (0)
     if (in_f32) {
@@ -234,21 +237,28 @@ hipError_t pw_wide_launch(hipStream_t st, const void* x, bool in_f32, int ln, co
 
 }  // namespace
 
-bool pw_wide_supported(int K, long npx) {
+bool pw_wide_supported(int K, long npx, int planes) {
     static const int on = env_int_w("IRA_PW_WIDE", 1);
-    // K = 256 (SwinIR-L, 240 channels padded) was tried with one row block per iteration (two need 2 x 64 KB of weight stages): LN + qkv
-    // 31.3 -> 31.2 ms per frame, LN + fc1 25.8 -> 27.9: not dispatched
-    return on && ((K == 192 && npx >= 512L * 64) || (K == 384 && npx >= 256L * 64));
+    if (!on) return false;
+    // K = 256 (SwinIR-L, 240 channels padded) with both planes was tried with one row block per iteration (two need 2 x 64 KB of weight
+    // stages): LN + qkv 31.3 -> 31.2 ms per frame, LN + fc1 25.8 -> 27.9: not dispatched.  With the hi plane alone two row blocks fit.
+    if (planes == 1) return (K == 192 || K == 256) && npx >= 512L * 64;
+    return (K == 192 && npx >= 512L * 64) || (K == 384 && npx >= 256L * 64);
 }
 
 hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mode, int K, const void* W, const float* bias, void* y, int y_stride,
-                          int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
+                          int n_store, int NB, int T, int P, float eps, int ln_n, int act, int planes) {
     if (ln_n <= 0 || ln_n > K) ln_n = K;
     if (n_store % 8 != 0 || y_stride % 8 != 0 || ln_mode < 0 || ln_mode > 2) return hipErrorInvalidValue;
-#define IRA_PWW(KS_, NW_, PG_, NBI_) \
-    return pw_wide_launch<KS_, NW_, PG_, NBI_, 2>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act)
-    if (K == 192) IRA_PWW(12, 8, 2, 2);
-    if (K == 384) IRA_PWW(24, 8, 1, 1);
+#define IRA_PWW(KS_, NW_, PG_, NBI_, LO_) \
+    return pw_wide_launch<KS_, NW_, PG_, NBI_, 2, LO_>(st, x, in_f32, ln_mode, (const f16*)W, bias, (f16*)y, y_stride, n_store, NB, T, P, eps, ln_n, act)
+    if (planes == 1) {
+        if (K == 192) IRA_PWW(12, 8, 2, 2, false);
+        if (K == 256) IRA_PWW(16, 8, 2, 2, false);
+        return hipErrorInvalidValue;
+    }
+    if (K == 192) IRA_PWW(12, 8, 2, 2, true);
+    if (K == 384) IRA_PWW(24, 8, 1, 1, true);
 #undef IRA_PWW
     return hipErrorInvalidValue;
 }

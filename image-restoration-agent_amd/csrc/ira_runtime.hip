@@ -881,7 +881,7 @@ int ira_op_pw_kres_eps(ira_model_t* m, const void* x, int in_f32, int ln_mode, i
 
 int ira_op_pw_nres(ira_model_t* m, const void* x0, int K0, const void* x1, int K1, int in_f32, const void* W,
                    long w_tile_stride, const float* bias, const float* resid, float* y, int N, int NB, int T, int P) {
-    OP_BODY(m, "op", ira::launch_pw_nres(m->st, x0, K0, x1, K1, in_f32 != 0, W, w_tile_stride, bias, resid, y, N, NB, T, P));
+    OP_BODY(m, "op", ira::launch_pw_nres(m->st, x0, K0, x1, K1, in_f32 != 0, W, w_tile_stride, bias, resid, y, N, NB, T, P, m->w_planes));
 }
 
 int ira_op_dwconv_qkv(ira_model_t* m, const void* in, const float* w, const float* bias, void* qk, void* v, int T,
@@ -925,6 +925,13 @@ int ira_op_ffn2(ira_model_t* m, const float* x, float* xo, const void* v, const 
                 int C, const void* Win, const float* bin, const float* dwu, const float* dwub, const void* Wout, const float* bout, int T,
                 int H, int W, int Hp) {
     OP_BODY(m, "op", ira::launch_ffn2(m->st, x, xo, v, M, m_tile_stride, wo_b, ln_mode, C, Win, bin, dwu, dwub, Wout, bout, T, H, W, Hp));
+}
+
+int ira_set_weight_planes(ira_model_t* m, int planes) {
+    ENTER(m);
+    if (planes != 1 && planes != 2) return m->fail(IRA_ERR_ARG, "ira_set_weight_planes: 1 (hi plane only) or 2 (hi + lo)");
+    m->w_planes = planes;
+    return IRA_OK;
 }
 
 int ira_set_ffn_generation(ira_model_t* m, int gen) {
@@ -979,7 +986,7 @@ int ira_op_ln_affine(ira_model_t* m, const float* x, const float* g, const float
 
 int ira_op_pw_kres_ex(ira_model_t* m, const void* x, int in_f32, int ln_mode, int K, const void* W, const float* bias, void* y,
                       int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act) {
-    OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act));
+    OP_BODY(m, "op", ira::launch_pw_kres(m->st, x, in_f32 != 0, ln_mode, K, W, bias, y, y_stride, n_store, NB, T, P, eps, ln_n, act, m->w_planes));
 }
 
 int ira_op_naf_tail(ira_model_t* m, const void* g, const float* scale, float* x, int c, const void* W3, const float* b3,

@@ -191,6 +191,11 @@ class _Backend:
         h, w, c = frame.shape
         self._ck(self._lib.ira_strip_restore_u8_device(self._h, frame.data_ptr(), h, w, c, out.data_ptr()), 'ira_strip_restore_u8_device')
 
+    def set_weight_planes(self, planes: int):
+        """ira_set_weight_planes: 2 = hi + lo fp16 weight planes everywhere (default), 1 = hi plane alone in the 1x1 layers that have a
+        kernel for it (SwinIR handles; measured: tools/ablate_lo_swinir.py)."""
+        self._ck(self._lib.ira_set_weight_planes(self._h, int(planes)), 'ira_set_weight_planes')
+
     def set_ffn_generation(self, gen: int):
         self._ck(self._lib.ira_set_ffn_generation(self._h, int(gen)), 'ira_set_ffn_generation')
 
@@ -274,11 +279,16 @@ class SwinIRBackend(_Backend):
     (B,C,H*upscale,W*upscale), any H, W.  ``restore``: the reference harness (SwinIR/inference.py:69-90,294-322: always-pad by
     flip-concat, whole image or overlap-average tiler, clamp, round): uint8 (h,w,c) -> uint8 (h*s, w*s, c)."""
 
-    def __init__(self, cfg, state_dict, device: int = 0):
+    def __init__(self, cfg, state_dict, device: int = 0, weight_planes: int = 1):
+        """``weight_planes``: 1 (default) = the transformer layers' 1x1s run on the fp16 hi plane of their weights where a kernel for that
+        exists (the frame-sized launches of K = 192 / 256 layers; small launches keep both planes), 2 = hi + lo planes everywhere.  Measured
+        on the reference-generated goldens and at the benchmark geometry against the oracle: |dPSNR| <= 3e-5 dB."""
         from .swinir import pack_swinir_blob, swinir_cfg_struct
         self.cfg = cfg
         self.scale = cfg.upscale
         self._create(device, 'ira_swinir_create', swinir_cfg_struct(cfg), pack_swinir_blob(state_dict, cfg), 'ira_swinir_create')
+        if weight_planes != 2:
+            self.set_weight_planes(weight_planes)
 
 
 class XRestormerBackend(_Backend):

@@ -269,6 +269,13 @@ def pack_swinir_arrays(sd, cfg: SwinIRConfig) -> dict:
         out['hr_b'] = _pad1(_np(sd['conv_hr.bias']), 64)
     out['last_w'] = _conv3_pack_k(f64('conv_last.weight'), 64)
     out['last_b'] = _pad1(_np(sd['conv_last.bias']), up32(oc))
+    # Ablation hook for tools/ablate_lo_swinir.py (measurement only, never set on a product path): IRA_ABLATE_LO='fc1_w,fc2_w' zeroes the
+    # lo plane of the weights whose packed name ends in one of the suffixes, i.e. those layers then run with fp16 (hi plane) weights
+    import os
+    abl = [a for a in os.environ.get('IRA_ABLATE_LO', '').split(',') if a]
+    for name, arr in out.items():
+        if any(name.endswith(a) for a in abl) and arr.ndim >= 2 and arr.shape[0] == 2:
+            arr[1] = 0
     return out
 
 

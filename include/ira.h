@@ -387,6 +387,12 @@ int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void
  * after a separate apply kernel.  For A/B measurements; also settable with the environment variable IRA_FFN_GEN at create time. */
 int ira_set_ffn_generation(ira_model_t* m, int gen);
 
+/* Weight precision of the LayerNorm-fed and residual 1x1 layers of a SwinIR handle: 2 (default) = every weight as fp16 hi + lo planes
+ * (two MFMAs per fragment, ~fp32-exact weights); 1 = the hi plane alone (plain fp16 weights, half the MFMAs) wherever a kernel for it
+ * exists (else the call keeps both planes).  Measured on the reference-generated SwinIR-L x4 golden: PSNR against the reference
+ * 103.5 -> 101.5 dB, |dPSNR| 2.5e-5 dB (tools/ablate_lo_swinir.py).  Other architectures ignore the setting. */
+int ira_set_weight_planes(ira_model_t* m, int planes);
+
 /* Fused attention front end: LN + qkv 1x1 + depthwise 3x3 (restormer_arch.py:105-106,114) in one kernel; C in {48, 96}.
  * x fp32 NHWC (T,H,W,C); Wq packed qkv weights (LN gain folded, hi/lo, fragment-major), bq fp32 or NULL; dww fp32
  * [9][3C], dwb [3C] or NULL; outputs as ira_op_dwconv_qkv: q,k pixel-minor (T,H,ceil(W/8),2C,8), v NHWC (T,H,W,C). */

@@ -162,13 +162,17 @@ def test_swinir_large_x4_full_frame():
     h, w = 540, 960
     clean_hr, _ = O.synthetic_noisy_image(h * 4, w * 4, 3, sigma=10.0, seed=0)
     _, noisy = O.synthetic_noisy_image(h, w, 3, sigma=10.0, seed=0)
-    with SwinIRBackend(cfg, sd, device=0) as be:
+    with SwinIRBackend(cfg, sd, device=0) as be:                   # default: hi weight plane alone in the frame-sized 1x1 launches
         assert be.plan(h, w, None, 32)[:2] == (544, 968)
         got = be.restore(noisy, tile=None)
+        be.set_weight_planes(2)
+        got2 = be.restore(noisy, tile=None)                          # hi + lo planes everywhere
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     ref = S.swinir_restore_image(noisy, {k: torch.from_numpy(v) for k, v in sd.items()}, cfg.to_dict(), tile=None)
     assert got.shape == ref.shape == (h * 4, w * 4, 3)
-    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-    d = O.psnr_u8(got, clean_hr) - O.psnr_u8(ref, clean_hr)
-    print(f"SwinIR-L x4 960x540: u8 mismatch {float((diff != 0).mean()):.4f} max {int(diff.max())}, dPSNR {d:+.2e} dB")
-    assert diff.max() <= 1 and (diff > 0).mean() < 0.05 and abs(d) <= 1e-3
+    for name, g_ in (('hi plane', got), ('hi + lo', got2)):
+        diff = np.abs(g_.astype(np.int32) - ref.astype(np.int32))
+        d = O.psnr_u8(g_, clean_hr) - O.psnr_u8(ref, clean_hr)
+        print(f"SwinIR-L x4 960x540 ({name}): u8 mismatch {float((diff != 0).mean()):.4f} max {int(diff.max())}, dPSNR {d:+.2e} dB")
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.05 and abs(d) <= 1e-3
+    assert not np.array_equal(got, got2) or True                     # (the two may round to the same bytes; the kernels' own test is in test_gpu_ops)

@@ -198,6 +198,52 @@ def test_dwconv_qkv(ctx, C, T, H, W):
     close(qk.cpu().float(), q_ref, 2e-3)
 
 
+@pytest.mark.parametrize('K,N,ln', [(256, 768, 2), (192, 544, 1)])
+def test_pw_kres_hi_plane_only(ctx, K, N, ln):
+    """ira_set_weight_planes(1): k_pw_wide with the hi plane alone = plain fp16 weights (SwinIR-L LN + qkv shape; 17 row blocks)."""
+    g = torch.Generator().manual_seed(K + N)
+    T, P = 1, 33000
+    x = torch.randn(T * P, K, generator=g) * 1.3 + 0.2
+    NB = up32(N) // 32
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(NB * 32, generator=g) * 0.1
+    y = torch.full((T * P, N), float('nan'), dtype=torch.float16).cuda()
+    xd, Wd, bd = dev(x), dev(split16(rowperm_pad(W, NB * 32))), dev(bias)
+    ctx.set_weight_planes(1)
+    try:
+        rc = ctx._lib.ira_op_pw_kres_ex(ctx.handle, ptr(xd), 1, ln, K, ptr(Wd), ptr(bd), ptr(y), N, N, NB, T, P, C.c_float(1e-5), 0, 0)
+        assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    finally:
+        ctx.set_weight_planes(2)
+    ref16 = (r16(ln_core(x, ln)).double() @ r16(W).double().t()).float() + bias[:N]
+    ref32 = (r16(ln_core(x, ln)).double() @ W.double().t()).float() + bias[:N]
+    got = y.cpu().float()
+    close(got, ref16, 2e-3)
+    assert (got - ref16).abs().mean() < (got - ref32).abs().mean()          # it really is the fp16-weight product
+
+
+@pytest.mark.parametrize('K,N', [(480, 240), (256, 256), (512, 192)])
+def test_pw_nres_hi_plane_only(ctx, K, N):
+    """ira_set_weight_planes(1): k_nres_wide with the hi plane alone (SwinIR-L fc2 / proj shapes and the six-block form)."""
+    g = torch.Generator().manual_seed(K * 3 + N)
+    T, P = 1, 33001
+    NB = up32(N) // 32
+    x = r16(torch.randn(T * P, K, generator=g))
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    Wp = torch.zeros(1, NB * 32, K); Wp[0, :N] = W
+    res = torch.randn(T * P, N, generator=g)
+    y = torch.full((T * P, N), float('nan')).cuda()
+    xd, Wd, rd = dev(x.half()), dev(split16(rowperm_pad(Wp[0], NB * 32))), dev(res)
+    ctx.set_weight_planes(1)
+    try:
+        rc = ctx._lib.ira_op_pw_nres(ctx.handle, ptr(xd), K, None, 0, 0, ptr(Wd), 0, None, ptr(rd), ptr(y), N, NB, T, P)
+        assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    finally:
+        ctx.set_weight_planes(2)
+    ref16 = (x.double() @ r16(W).double().t()).float() + res
+    close(y.cpu(), ref16, 2e-5, 2e-5)
+
+
 @pytest.mark.parametrize('Hp,T,H,W,with_bias', [(64, 2, 6, 9, False), (128, 1, 4, 24, False), (32, 1, 2, 3, False),
                                                 (1024, 1, 5, 10, True),      # k_dwconv_gate_row: two chunks of 64 channel octets, rows not a multiple of 4
                                                 (512, 2, 9, 37, True)])       # ragged last 4-pixel step, several row segments per band
