@@ -42,7 +42,7 @@ hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int n
 
 // attn_scratch: fp32 [T][heads][c][c]
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
-                           float* attn_scratch, void* M, int T, int C, int heads, int S, int NB);
+                           float* attn_scratch, void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero = false);
 
 // Fused attention front end (ira_qkv_fused.hip): LN + qkv 1x1 + depthwise 3x3 -> q,k (pixel-minor) and v (NHWC).
 bool qkv_fused_supported(int C);

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_attn_softmax(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ attn, const float* __restrict__ wo,
-                                                   f16* __restrict__ M, int T, int C, int heads, int NB) {
+                                                   f16* __restrict__ M, int T, int C, int heads, int NB, int lo_zero) {
     extern __shared__ __attribute__((aligned(16))) float A[];   // [c][c]
     const int c = C / heads;
     const int hd = blockIdx.x % heads, t = blockIdx.x / heads;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void k_attn_fold(const float* __restrict__ att
         const long off = (((long)(o >> 5) * KT + (k >> 4)) * 64 + 32 * ((k >> 3) & 1) + rowperm(o & 31)) * 8 + (k & 7);
         const f16 hi = (f16)a;
         Mt[off] = hi;
-        Ml[off] = (f16)(a - (float)hi);
+        Ml[off] = lo_zero ? (f16)0.f : (f16)(a - (float)hi);      // lo_zero: the apply of this level runs on the hi plane alone (ira_set_weight_planes)
     }
 }
 
@@ -1805,14 +1805,14 @@ hipError_t launch_sum_records(hipStream_t st, const float* part, int S, int recl
 }
 
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, float* attn_scratch,
-                           void* M, int T, int C, int heads, int S, int NB) {
+                           void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero) {
     const int c = C / heads;
     if (c > 96) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_attn_softmax, dim3(T * heads, (c + 7) / 8), dim3(256), 0, st, part, temp, attn_scratch, T, C, heads, S);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_attn_fold, dim3(T * heads, (C + 15) / 16), dim3(256), (size_t)c * c * sizeof(float), st, attn_scratch, wo,
-                       (f16*)M, T, C, heads, NB);
+                       (f16*)M, T, C, heads, NB, m_lo_zero ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -227,6 +227,8 @@ int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, floa
 bool dn_bind_weights(ira_model* m);
 int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool sw_bind_weights(ira_model* m);
+int sw_zero_lo_planes(ira_model* m);          // ira_set_weight_planes(1) on a SwinIR handle
+int restormer_zero_lo_planes(ira_model* m);   // ... on a Restormer / X-Restormer handle (levels with C = 192 / 384 only)
 int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool rr_bind_weights(ira_model* m);
 int rr_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);

@@ -242,7 +242,7 @@ bool pw_wide_supported(int K, long npx, int planes) {
     if (!on) return false;
     // K = 256 (SwinIR-L, 240 channels padded) with both planes was tried with one row block per iteration (two need 2 x 64 KB of weight
     // stages): LN + qkv 31.3 -> 31.2 ms per frame, LN + fc1 25.8 -> 27.9: not dispatched.  With the hi plane alone two row blocks fit.
-    if (planes == 1) return (K == 192 || K == 256) && npx >= 512L * 64;
+    if (planes == 1) return ((K == 192 || K == 256) && npx >= 512L * 64) || (K == 384 && npx >= 256L * 64);
     return (K == 192 && npx >= 512L * 64) || (K == 384 && npx >= 256L * 64);
 }
 
@@ -255,6 +255,7 @@ hipError_t launch_pw_wide(hipStream_t st, const void* x, bool in_f32, int ln_mod
     if (planes == 1) {
         if (K == 192) IRA_PWW(12, 8, 2, 2, false);
         if (K == 256) IRA_PWW(16, 8, 2, 2, false);
+        if (K == 384) IRA_PWW(24, 8, 1, 2, false);      // two row blocks per iteration fit with one plane: whole-line stores
         return hipErrorInvalidValue;
     }
     if (K == 192) IRA_PWW(12, 8, 2, 2, true);

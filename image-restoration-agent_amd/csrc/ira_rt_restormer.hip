@@ -162,6 +162,38 @@ static int ensure_workspace(ira_model* m, int T, int H, int W) {
     return IRA_OK;
 }
 
+// ira_set_weight_planes(1): the 1x1 layers of the levels that have hi-plane kernels (C = 192 / 384: k_pw_wide, k_nres_wide) run on fp16
+// weights.  The lo planes of exactly those weights are ZEROED in the handle's copy of the blob, so that the small launches that still go
+// through two-plane kernels compute the same numbers (x * 0 adds nothing): a tile's result stays independent of its launch batch.
+static bool hi_plane_level(int C) { return C == 192 || C == 384; }
+
+int restormer_zero_lo_planes(ira_model* m) {
+    const ira_restormer_config& c = m->cfg;
+    auto zero = [&](const void* w, size_t total) -> hipError_t {
+        return w ? hipMemsetAsync((char*)const_cast<void*>(w) + total / 2, 0, total / 2, m->st) : hipSuccess;
+    };
+    std::vector<Blk>* stages[8] = {&m->enc1, &m->enc2, &m->enc3, &m->lat, &m->dec3, &m->dec2, &m->dec1, &m->refine};
+    const int lvl[8] = {0, 1, 2, 3, 2, 1, 0, 0};
+    for (int si = 0; si < 8; ++si) {
+        const int l = lvl[si];
+        const int C = (si >= 6) ? (c.dim << 1) : (c.dim << l);        // decoder level 1 and the refinement stage run at 2 * dim
+        if (!hi_plane_level(C)) continue;
+        const size_t Hp = up32((si >= 6) ? c.hidden[1] : c.hidden[l]), NBq = up32(3 * C), NBc = up32(C);
+        for (Blk& b : *stages[si]) {
+            HIP_TRY(m, zero(b.qkv_w, 2 * NBq * C * 2));
+            HIP_TRY(m, zero(b.pin_w, (size_t)2 * 2 * Hp * C * 2));
+            HIP_TRY(m, zero(b.pout_w, 2 * NBc * Hp * 2));
+            if (m->xr) {
+                // (the OCAB 1x1s keep both planes: their K = 16 * heads has no hi-plane kernel)
+                HIP_TRY(m, zero(b.pin2_w, (size_t)2 * 2 * Hp * C * 2));
+                HIP_TRY(m, zero(b.pout2_w, 2 * NBc * Hp * 2));
+            }
+        }
+    }
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    return IRA_OK;
+}
+
 // GDFN + residual (restormer_arch.py:88-93,149): fused kernel where supported (writes x -> alt, the two are swapped), else three kernels.
 // v != nullptr: the attention apply x += M_t . v (+ wo_b) of the same block has NOT been run and is folded into the fused kernel
 // (ira_ffn2.hip); callers pass it only when ffn2_usable() said yes.
@@ -197,9 +229,9 @@ static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const fl
         std::swap(x, alt);
         return IRA_OK;
     }
-    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, pin_w, pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P));
+    RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, pin_w, pin_b, m->hp, 2 * Hp, 2 * Hp, 2 * Hp / 32, T, P, 1e-5f, 0, 0, hi_plane_level(C) ? m->w_planes : 2));
     RUN(m, k_[1], ira::launch_dwconv_gate(st, m->hp, dw_w, dw_b, m->g, T, H, W, Hp));
-    RUN(m, k_[2], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, pout_w, 0, pout_b, x, x, C, NBc, T, P));
+    RUN(m, k_[2], ira::launch_pw_nres(st, m->g, Hp, nullptr, 0, false, pout_w, 0, pout_b, x, x, C, NBc, T, P, hi_plane_level(C) ? m->w_planes : 2));
     return IRA_OK;
 }
 
@@ -250,7 +282,7 @@ static int strip_gram_mix(ira_model* m, const Blk& b, int H, int W, int C, int h
         HIP_TRY(m, hipStreamSynchronize(m->st));
         if (cm.allgather(cm.ctx, nbytes) != 0) return m->fail(IRA_ERR_COMM, "strip Gram all-gather callback failed");
     }
-    RUN(m, km, ira::launch_attn_mix(m->st, (const float*)cm.gather_recv, b.wo, b.temp, m->attnA, m->M, 1, C, heads, cm.world, NBc));
+    RUN(m, km, ira::launch_attn_mix(m->st, (const float*)cm.gather_recv, b.wo, b.temp, m->attnA, m->M, 1, C, heads, cm.world, NBc, m->w_planes == 1 && hi_plane_level(C)));
     return IRA_OK;
 }
 
@@ -279,21 +311,21 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
         if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
         RUN(m, kq, ira::launch_qkv_fused(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
     } else {
-        RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P));
+        RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P, 1e-5f, 0, 0, hi_plane_level(C) ? m->w_planes : 2));
         RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));
     }
     if (m->strip_on) {
         if ((rc = strip_gram_mix(m, b, H, W, C, heads, lv, k_[2], k_[3])) != IRA_OK) return rc;
     } else {
         RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-        RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc));
+        RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc, m->w_planes == 1 && hi_plane_level(C)));
     }
     // attention apply x += M_t . v (:127-131 as a per-tile 1x1) and GDFN (:88-93): ONE kernel where the second-generation fused
     // kernel runs (not in band mode: the halo row of x has to be exchanged between the two there)
     const long m_stride = 2L * NBc * 32 * C;
     const bool fold = !m->strip_on && ffn2_usable(m, b.dw2_u, b.dw2_ub, b.dw2_b, alt, C, Hp);
     if (!fold) {
-        RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, m_stride, b.wo_b, x, x, C, NBc, T, P));
+        RUN(m, k_[4], ira::launch_pw_nres(st, m->v, C, nullptr, 0, false, m->M, m_stride, b.wo_b, x, x, C, NBc, T, P, hi_plane_level(C) ? m->w_planes : 2));
         if ((rc = strip_halo(m, x, H, W, C, lv)) != IRA_OK) return rc;
     }
     rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.dw2_u, b.dw2_ub, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp,

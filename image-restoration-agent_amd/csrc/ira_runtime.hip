@@ -930,7 +930,14 @@ int ira_op_ffn2(ira_model_t* m, const float* x, float* xo, const void* v, const 
 int ira_set_weight_planes(ira_model_t* m, int planes) {
     ENTER(m);
     if (planes != 1 && planes != 2) return m->fail(IRA_ERR_ARG, "ira_set_weight_planes: 1 (hi plane only) or 2 (hi + lo)");
-    m->w_planes = planes;
+    if (planes == m->w_planes) return IRA_OK;
+    if (planes == 2) return m->fail(IRA_ERR_ARG, "ira_set_weight_planes: the lo planes of this handle were zeroed by an earlier call with 1; create a new handle for hi + lo weights");
+    int rc = IRA_OK;
+    if (m->arch == 0) rc = restormer_zero_lo_planes(m);          // Restormer / X-Restormer: levels with C = 192 / 384
+    else if (m->arch == 3) rc = sw_zero_lo_planes(m);
+    else return IRA_OK;                                          // other architectures have no hi-plane kernels: the setting is ignored
+    if (rc != IRA_OK) return rc;
+    m->w_planes = 1;
     return IRA_OK;
 }
 

@@ -91,23 +91,25 @@ def attention_mix(q, k, temperature, wo, heads):
 def block(x, sd, p, heads, ln_type, ct: Contract):
     c = x.shape[1]
     lnb1 = sd.get(f'{p}.norm1.body.bias')
-    wq, bq = fold_ln(sd[f'{p}.attn.qkv.weight'], sd[f'{p}.norm1.body.weight'], lnb1, ct, 'w_qkv')
+    # per-layer weight tags carry a '_deep' suffix on levels 3-4 (encoder_level3, latent, decoder_level3): the lo-plane ablation per level
+    dp = '_deep' if ('level3' in p or p.startswith('latent')) else ''
+    wq, bq = fold_ln(sd[f'{p}.attn.qkv.weight'], sd[f'{p}.norm1.body.weight'], lnb1, ct, 'w_qkv' + dp)
     xn = ct.act(ln_core(x, ln_type), 'xn1')
     qkv_pre = ct.act(conv1x1(xn, wq, bq), 'qkv_pre')
     qkv = F.conv2d(qkv_pre, ct.w(sd[f'{p}.attn.qkv_dwconv.weight'], 'dw1w'), padding=1, groups=3 * c)
     q, k, v = qkv.chunk(3, dim=1)
     q, k, v = ct.act(q, 'qk'), ct.act(k, 'qk'), ct.act(v, 'v')
-    m = ct.w(attention_mix(q, k, sd[f'{p}.attn.temperature'], sd[f'{p}.attn.project_out.weight'], heads), 'M')
+    m = ct.w(attention_mix(q, k, sd[f'{p}.attn.temperature'], sd[f'{p}.attn.project_out.weight'], heads), 'M' if not dp else 'w_M_deep')
     x = ct.res(x + torch.einsum('bchw,boc->bohw', v, m), 'res_attn')
 
     lnb2 = sd.get(f'{p}.norm2.body.bias')
-    wi, bi = fold_ln(sd[f'{p}.ffn.project_in.weight'], sd[f'{p}.norm2.body.weight'], lnb2, ct, 'w_pin')
+    wi, bi = fold_ln(sd[f'{p}.ffn.project_in.weight'], sd[f'{p}.norm2.body.weight'], lnb2, ct, 'w_pin' + dp)
     xn = ct.act(ln_core(x, ln_type), 'xn2')
     hp = ct.act(conv1x1(xn, wi, bi), 'hp')
     hd = F.conv2d(hp, ct.w(sd[f'{p}.ffn.dwconv.weight'], 'dw2w'), padding=1, groups=hp.shape[1])
     h1, h2 = hd.chunk(2, dim=1)
     g = ct.act(F.gelu(h1) * h2, 'g')
-    x = ct.res(x + conv1x1(g, ct.w(sd[f'{p}.ffn.project_out.weight'][:, :, 0, 0], 'w_pout')), 'res_ffn')
+    x = ct.res(x + conv1x1(g, ct.w(sd[f'{p}.ffn.project_out.weight'][:, :, 0, 0], 'w_pout' + dp)), 'res_ffn')
     return x
 
 

@@ -26,7 +26,7 @@ def ctx():
     from ira_amd.config import reduced_config
     from ira_amd.weights import seeded_state_dict
     cfg = reduced_config('BiasFree')
-    be = RestormerBackend(cfg, seeded_state_dict(cfg, 1), device=0)
+    be = RestormerBackend(cfg, seeded_state_dict(cfg, 1), device=0, weight_planes=2)      # the op tests check hi + lo kernels; hi-plane kernels: _hi_plane_ctx
     yield be
     be.close()
 
@@ -198,6 +198,15 @@ def test_dwconv_qkv(ctx, C, T, H, W):
     close(qk.cpu().float(), q_ref, 2e-3)
 
 
+def _hi_plane_ctx():
+    """A handle whose op entry points run with ira_set_weight_planes(1) (sticky per handle: not the shared fixture)."""
+    from ira_amd.backend import RestormerBackend
+    from ira_amd.config import reduced_config
+    from ira_amd.weights import seeded_state_dict
+    cfg = reduced_config()
+    return RestormerBackend(cfg, seeded_state_dict(cfg, 1), device=0, weight_planes=1)
+
+
 @pytest.mark.parametrize('K,N,ln', [(256, 768, 2), (192, 544, 1)])
 def test_pw_kres_hi_plane_only(ctx, K, N, ln):
     """ira_set_weight_planes(1): k_pw_wide with the hi plane alone = plain fp16 weights (SwinIR-L LN + qkv shape; 17 row blocks)."""
@@ -209,12 +218,9 @@ def test_pw_kres_hi_plane_only(ctx, K, N, ln):
     bias = torch.randn(NB * 32, generator=g) * 0.1
     y = torch.full((T * P, N), float('nan'), dtype=torch.float16).cuda()
     xd, Wd, bd = dev(x), dev(split16(rowperm_pad(W, NB * 32))), dev(bias)
-    ctx.set_weight_planes(1)
-    try:
-        rc = ctx._lib.ira_op_pw_kres_ex(ctx.handle, ptr(xd), 1, ln, K, ptr(Wd), ptr(bd), ptr(y), N, N, NB, T, P, C.c_float(1e-5), 0, 0)
-        assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
-    finally:
-        ctx.set_weight_planes(2)
+    with _hi_plane_ctx() as c1:
+        rc = c1._lib.ira_op_pw_kres_ex(c1.handle, ptr(xd), 1, ln, K, ptr(Wd), ptr(bd), ptr(y), N, N, NB, T, P, C.c_float(1e-5), 0, 0)
+        assert rc == 0, c1._lib.ira_last_error(c1.handle)
     ref16 = (r16(ln_core(x, ln)).double() @ r16(W).double().t()).float() + bias[:N]
     ref32 = (r16(ln_core(x, ln)).double() @ W.double().t()).float() + bias[:N]
     got = y.cpu().float()
@@ -234,12 +240,9 @@ def test_pw_nres_hi_plane_only(ctx, K, N):
     res = torch.randn(T * P, N, generator=g)
     y = torch.full((T * P, N), float('nan')).cuda()
     xd, Wd, rd = dev(x.half()), dev(split16(rowperm_pad(Wp[0], NB * 32))), dev(res)
-    ctx.set_weight_planes(1)
-    try:
-        rc = ctx._lib.ira_op_pw_nres(ctx.handle, ptr(xd), K, None, 0, 0, ptr(Wd), 0, None, ptr(rd), ptr(y), N, NB, T, P)
-        assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
-    finally:
-        ctx.set_weight_planes(2)
+    with _hi_plane_ctx() as c1:
+        rc = c1._lib.ira_op_pw_nres(c1.handle, ptr(xd), K, None, 0, 0, ptr(Wd), 0, None, ptr(rd), ptr(y), N, NB, T, P)
+        assert rc == 0, c1._lib.ira_last_error(c1.handle)
     ref16 = (x.double() @ r16(W).double().t()).float() + res
     close(y.cpu(), ref16, 2e-5, 2e-5)
 

@@ -5,7 +5,7 @@ import torch
 from ira_amd.backend import RestormerBackend
 from ira_amd.config import reduced_config
 from ira_amd.weights import seeded_state_dict
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1)); L = be._lib
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2"))); L = be._lib
 p = lambda t: C.c_void_p(t.data_ptr())
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 for name, mode, H, K, N in (('up 2->1', 2, 256, 96, 192), ('up 3->2', 2, 128, 192, 384), ('up 4->3', 2, 64, 384, 768),

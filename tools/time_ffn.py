@@ -6,7 +6,7 @@ from ira_amd.backend import RestormerBackend
 from ira_amd.config import reduced_config, RestormerConfig
 from ira_amd.weights import seeded_state_dict
 from ira_amd.pack import pack_block
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1))
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2")))
 Cc, hid, T, H, W = int(os.environ.get('C', 96)), int(os.environ.get('HID', 255)), 8, 512, 512
 Hp = (hid + 31) // 32 * 32
 g = torch.Generator().manual_seed(0)

@@ -13,7 +13,7 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 hid = int(os.environ.get("FFN_HID", int(Cc * 2.66)))
 H = W = 512
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1))
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2")))
 Hp = (hid + 31) // 32 * 32
 NBc = (Cc + 31) // 32
 g = torch.Generator().manual_seed(0)

@@ -5,7 +5,7 @@ import torch
 from ira_amd.backend import RestormerBackend
 from ira_amd.config import reduced_config
 from ira_amd.weights import seeded_state_dict
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1)); L = be._lib
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2"))); L = be._lib
 p = lambda t: C.c_void_p(t.data_ptr())
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 for name, P, K, N, per_tile in (('L3 pout', 128 * 128, 512, 192, 0), ('L4 pout', 64 * 64, 1024, 384, 0), ('L3 apply', 128 * 128, 192, 192, 1), ('L4 apply', 64 * 64, 384, 384, 1)):

@@ -6,7 +6,7 @@ from ira_amd.backend import RestormerBackend
 from ira_amd.config import reduced_config
 from ira_amd.weights import seeded_state_dict
 act = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1)); L = be._lib
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2"))); L = be._lib
 p = lambda t: C.c_void_p(t.data_ptr())
 for name, T, P, K, N, f32, ln in (('L3 ln_pin', 40, 128 * 128, 192, 1024, 1, 1), ('L4 ln_pin', 40, 64 * 64, 384, 2048, 1, 1),
                                   ('L3 ln_qkv', 40, 128 * 128, 192, 576, 1, 1), ('L4 ln_qkv', 40, 64 * 64, 384, 1152, 1, 1),

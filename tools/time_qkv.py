@@ -6,7 +6,7 @@ from ira_amd.backend import RestormerBackend
 from ira_amd.config import reduced_config, RestormerConfig
 from ira_amd.weights import seeded_state_dict
 from ira_amd.pack import pack_block
-cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1))
+cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2")))
 Cc, hid, T, H, W = 96, 32, 8, 512, 512
 g = torch.Generator().manual_seed(0)
 sd = {'b.norm1.body.weight': torch.ones(Cc), 'b.norm2.body.weight': torch.ones(Cc), 'b.attn.temperature': torch.ones(1, 1, 1),
