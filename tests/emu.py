@@ -113,8 +113,9 @@ def block(x, sd, p, heads, ln_type, ct: Contract):
     return x
 
 
-def conv3x3(x, w, ct):
-    return F.conv2d(ct.act(x, 'c3in'), ct.w(w, 'c3w'), padding=1)
+def conv3x3(x, w, ct, deep=False):
+    # deep: the convolutions between levels 2-3-4 (down2_3, down3_4, up4_3, up3_2) carry their own weight tag for the per-level ablation
+    return F.conv2d(ct.act(x, 'c3in'), ct.w(w, 'w_c3_deep' if deep else 'c3w'), padding=1)
 
 
 def forward(inp, sd, cfg, ct: Contract, taps=None):
@@ -133,13 +134,13 @@ def forward(inp, sd, cfg, ct: Contract, taps=None):
         taps['patch_embed'] = x1
     e1 = stage(x1, 'encoder_level1', nb[0], heads[0])
     e2 = stage(ct.res(F.pixel_unshuffle(conv3x3(e1, sd['down1_2.body.0.weight'], ct), 2)), 'encoder_level2', nb[1], heads[1])
-    e3 = stage(ct.res(F.pixel_unshuffle(conv3x3(e2, sd['down2_3.body.0.weight'], ct), 2)), 'encoder_level3', nb[2], heads[2])
-    lat = stage(ct.res(F.pixel_unshuffle(conv3x3(e3, sd['down3_4.body.0.weight'], ct), 2)), 'latent', nb[3], heads[3])
+    e3 = stage(ct.res(F.pixel_unshuffle(conv3x3(e2, sd['down2_3.body.0.weight'], ct, True), 2)), 'encoder_level3', nb[2], heads[2])
+    lat = stage(ct.res(F.pixel_unshuffle(conv3x3(e3, sd['down3_4.body.0.weight'], ct, True), 2)), 'latent', nb[3], heads[3])
 
-    u3 = ct.act(F.pixel_shuffle(conv3x3(lat, sd['up4_3.body.0.weight'], ct), 2))
+    u3 = ct.act(F.pixel_shuffle(conv3x3(lat, sd['up4_3.body.0.weight'], ct, True), 2))
     d3 = ct.res(conv1x1(torch.cat([u3, ct.act(e3)], 1), ct.w(sd['reduce_chan_level3.weight'][:, :, 0, 0])))
     d3 = stage(d3, 'decoder_level3', nb[2], heads[2])
-    u2 = ct.act(F.pixel_shuffle(conv3x3(d3, sd['up3_2.body.0.weight'], ct), 2))
+    u2 = ct.act(F.pixel_shuffle(conv3x3(d3, sd['up3_2.body.0.weight'], ct, True), 2))
     d2 = ct.res(conv1x1(torch.cat([u2, ct.act(e2)], 1), ct.w(sd['reduce_chan_level2.weight'][:, :, 0, 0])))
     d2 = stage(d2, 'decoder_level2', nb[1], heads[1])
     u1 = ct.res(F.pixel_shuffle(conv3x3(d2, sd['up2_1.body.0.weight'], ct), 2))
