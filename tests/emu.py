@@ -44,10 +44,14 @@ class Contract:
         return r16(t) if self._on(tag) else t
 
 
-def GPU_CONTRACT():
+DEEP_HI_PLANE = ['w_pin_deep', 'w_qkv_deep', 'w_pout_deep', 'w_M_deep']
+
+
+def GPU_CONTRACT(dim=None):
     """What csrc/ implements: fp32 residual stream, fp16 branch activations, weights as fp16 hi + lo
-    planes (~exact), dense 3x3 inputs split hi/lo in registers (~exact)."""
-    return Contract(res_fp16=False, act_fp16=True, off=['w', 'M', 'c3w', 'c3in', 'dw1w', 'dw2w'])
+    planes (~exact), dense 3x3 inputs split hi/lo in registers (~exact); with the default weight_planes = 1 the 1x1 layers of the levels
+    with 192 / 384 channels (levels 3-4 when dim = 48) run on plain fp16 weights."""
+    return Contract(res_fp16=False, act_fp16=True, off=['w', 'M', 'c3w', 'c3in', 'dw1w', 'dw2w'], on=DEEP_HI_PLANE if dim == 48 else ())
 
 
 def ln_core(x, ln_type):

@@ -73,7 +73,7 @@ def test_forward_matches_contract_emulator(name, cfgf, seed, H, W, B):
     x = (torch.rand(B, cfg.inp_channels, H, W, generator=g) * 255).round() / 255
     y = be.forward(x.numpy())
     with torch.no_grad():
-        ye = emu.forward(x, sd, cfg.to_dict(), emu.GPU_CONTRACT()).numpy()
+        ye = emu.forward(x, sd, cfg.to_dict(), emu.GPU_CONTRACT(cfg.dim)).numpy()
         yo = O.restormer_forward(x, sd, cfg.to_dict()).numpy()
     pe, po = O.psnr_f(y, ye), O.psnr_f(y, yo)
     print(f"{name}: PSNR vs emulator {pe:.2f} dB, vs fp32 oracle {po:.2f} dB (emulator vs oracle {O.psnr_f(ye, yo):.2f})")
