@@ -687,20 +687,39 @@ def main():
     n_tiles = n_rows * n_cols
     whole = args.workload == 'restormer4k_whole'
     gather = None
+    data_path = 'rccl in libira_hip.so (ira_comm_init + ira_restore_frame_distributed)'
     if world > 1:
         if backend == 'nccl':
             from ira_amd.dist import init_comm
-            init_comm(be, rank, world)                # ncclCommInitRank inside the library; the id travels over a TCP socket
+            ok = 1
+            try:
+                init_comm(be, rank, world)            # ncclCommInitRank inside the library; the id travels over a TCP socket
+            except Exception as e:                    # never run on > 1 GPU by the builder: keep the bench alive and say what happened
+                print(f"[bench rank {rank}] library communicator failed: {e!r}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                  # every rank takes the same path
+            if int(flag.item()) == 0:
+                # fallback: the same tile partition, the all-gather issued by torch.distributed's own RCCL group on device tensors
+                if be.has_comm:
+                    be.comm_destroy()
+                from ira_amd.test_transports import GlooTileGather
+                gather = GlooTileGather(group=dist.new_group(backend='nccl'), via_host=False)
+                data_path = 'FALLBACK: torch.distributed nccl all_gather (the library communicator could not be created: see stderr)'
         else:
             from ira_amd.test_transports import GlooTileGather
             gather = GlooTileGather(via_host=True)
+            data_path = 'gloo rehearsal on one GPU (never a result)'
     rst = TileParallelRestorer(be, rank, world, gather=gather)
     if whole and world > 1:
         # the untiled frame in `world` horizontal bands; halo rows and Gram records by ncclSend / ncclRecv / ncclAllGather
         # on the model's stream (ira_strip_restore_u8_device)
         from ira_amd.dist import StripParallelRestorer
-        if backend == 'nccl':
+        if backend == 'nccl' and gather is None:
             srst = StripParallelRestorer(be, rank, world)
+        elif backend == 'nccl':
+            from ira_amd.test_transports import TorchDistTransport
+            srst = StripParallelRestorer(be, rank, world, transport=TorchDistTransport(rank, world, group=gather.group, via_host=False))
         else:
             from ira_amd.test_transports import TorchDistTransport
             srst = StripParallelRestorer(be, rank, world, transport=TorchDistTransport(rank, world, via_host=True))
@@ -748,7 +767,8 @@ def main():
                                    + (f'{world} horizontal band(s) with halo-row and Gram exchange' if whole else f'tile-parallel over {world} GPU(s)'),
                        'frames_per_s': round(value / mp_out, 4), 'tiles': n_tiles,
                        'device_ms_per_step_rank0': round(dev_ms / args.steps, 3),
-                       'timed_region': 'frame resident in HBM before the timed region, uint8 result left in HBM; the H2D / D2H copies of the host-buffer entry (24.9 MB each way) are outside it'},
+                       'timed_region': 'frame resident in HBM before the timed region, uint8 result left in HBM; the H2D / D2H copies of the host-buffer entry (24.9 MB each way) are outside it',
+                       **({'collective': data_path} if world > 1 else {})},
             'net_roofline': {'bound': 'hbm', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
                              'achieved': round(net_bytes / 1e9 / (elapsed / args.steps) / world, 1), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s per GPU', 'frac': round(net_bytes / 1e9 / (elapsed / args.steps) / world / HBM_PEAK_GBS, 4)},
