@@ -67,6 +67,11 @@ bool nres_wide_supported(int K, int N, int NB, int T, int P, long w_tile_stride)
 hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W, long w_tile_stride, const float* bias, const float* resid, float* y,
                             int N, int NB, int T, int P, int planes = 2);
 
+// ira_swin_mlp.hip: x += fc2(GELU(fc1(LayerNorm(x)))) in one kernel for 256 padded channels (SwinIR-L), in place on the fp32 token stream
+bool swin_mlp_supported(int Cp, int hidp, long npx);
+hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int Cp, int hidp, long npx,
+                           float eps, int ln_n, int planes);
+
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);
 

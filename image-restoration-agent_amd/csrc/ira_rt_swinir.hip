@@ -185,6 +185,12 @@ int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float
             RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0, m->w_planes));
             RUN(m, k_[1], ira::launch_swin_attn(st, m->sw_qkv, b.bias_tab, m->sw_att, T, Hp, Wp, heads, ws, shift));
             RUN(m, k_[2], ira::launch_pw_nres(st, m->sw_att, Kh, nullptr, 0, false, b.proj_w, 0, b.proj_b, x, x, g.Cp, g.Cp / 32, T, P, m->w_planes));
+            if (ira::swin_mlp_supported(g.Cp, g.hidp, (long)T * P)) {      // LN + fc1 + GELU + fc2 + residual in one kernel: the hidden tensor never exists
+                char km[64];
+                if (m->profile) snprintf(km, sizeof km, "swin_mlp_fused|C%d|%dx%d|T%d", g.C, Hp, Wp, T); else km[0] = 0;
+                RUN(m, km, ira::launch_swin_mlp(st, x, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, g.Cp, g.hidp, (long)T * P, 1e-5f, g.C, m->w_planes));
+                continue;
+            }
             RUN(m, k_[3], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.fc1_w, b.fc1_b, m->sw_hid, g.hidp, g.hidp, g.hidp / 32, T, P, 1e-5f, g.C, 1, m->w_planes));
             RUN(m, k_[4], ira::launch_pw_nres(st, m->sw_hid, g.hidp, nullptr, 0, false, b.fc2_w, 0, b.fc2_b, x, x, g.Cp, g.Cp / 32, T, P, m->w_planes));
         }

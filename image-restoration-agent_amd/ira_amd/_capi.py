@@ -139,6 +139,7 @@ SIGNATURES = {
     'ira_op_swin_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     'ira_op_ln_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, C.c_float]),
     'ira_op_pw_kres_ex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i]),
+    'ira_op_swin_mlp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, C.c_float, _i]),
     'ira_op_naf_tail': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'ira_op_naf_sca': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i]),
 }

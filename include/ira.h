@@ -441,6 +441,13 @@ int ira_op_ln_affine(ira_model_t* m, const float* x_dev, const float* g_dev, con
 int ira_op_pw_kres_ex(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode, int K, const void* W_f16_dev, const float* bias_dev,
                       void* y_f16_dev, int y_stride, int n_store, int NB, int T, int P, float eps, int ln_n, int act);
 
+/* SwinIR MLP half-block in place on the fp32 token stream x (npx, Cp = 256):  x += fc2(GELU(fc1(LayerNorm(x))))
+ * (network_swinir.py:274-277, Mlp :14-30; LayerNorm gain/bias folded into fc1 by the packer, ln_n = real channels).  W1 [2][hidp/32][16][64][8],
+ * b1 fp32 [hidp], W2 [2][8][hidp/16][64][8], b2 fp32 [256]; the hidden activations stay on chip.  Same result, bit for bit, as
+ * ira_op_pw_kres_ex(act 1) into an fp16 (npx, hidp) tensor followed by ira_op_pw_nres on it.  npx >= 32768. */
+int ira_op_swin_mlp(ira_model_t* m, float* x_dev, const void* W1_f16_dev, const float* b1_dev, const void* W2_f16_dev, const float* b2_dev,
+                    int Cp, int hidp, long npx, float eps, int ln_n);
+
 /* ---- NAFNet kernels (NAFNet_arch.py:158-326)
  * Pointwise contraction on an MFMA pixel grid of T x Hg x Wg pixels, W packed like every 1x1 here
  * ([2 planes][NBtot][K/16][64][8], per image if w_tile_stride != 0), fp32 result.

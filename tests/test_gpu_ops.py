@@ -247,6 +247,43 @@ def test_pw_nres_hi_plane_only(ctx, K, N):
     close(y.cpu(), ref16, 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize('planes,npx', [(2, 32768 + 77), (1, 40000)])
+def test_swin_mlp_fused(ctx, planes, npx):
+    """k_swin_mlp (network_swinir.py:274-277, Mlp :14-30): x += fc2(GELU(fc1(LN(x)))) with the hidden activations on chip, against
+    (a) the two kernels it replaces through an fp16 hidden tensor - bit for bit - and (b) a torch fp32 statement with the same rounding
+    points (fp16 LayerNorm output, fp16 hidden).  Ragged last workgroup; 240 real of 256 channels as SwinIR-L."""
+    g = torch.Generator().manual_seed(planes * 7 + 1)
+    Cp, Cr, hid = 256, 240, 480
+    x = torch.zeros(npx, Cp); x[:, :Cr] = torch.randn(npx, Cr, generator=g) * 1.5 + 0.3
+    W1 = torch.zeros(hid, Cp); W1[:, :Cr] = torch.randn(hid, Cr, generator=g) / Cr ** 0.5
+    W2 = torch.zeros(Cp, hid); W2[:Cr] = torch.randn(Cr, hid, generator=g) / hid ** 0.5
+    b1 = torch.randn(hid, generator=g) * 0.1
+    b2 = torch.zeros(Cp); b2[:Cr] = torch.randn(Cr, generator=g) * 0.1
+    W1d, W2d, b1d, b2d = dev(split16(W1)), dev(split16(W2)), dev(b1), dev(b2)
+    xa, xb = dev(x), dev(x)
+    hbuf = torch.empty(npx, hid, dtype=torch.float16).cuda()
+    be = ctx if planes == 2 else _hi_plane_ctx()
+    try:
+        L, h = be._lib, be.handle
+        rc = L.ira_op_swin_mlp(h, ptr(xa), ptr(W1d), ptr(b1d), ptr(W2d), ptr(b2d), Cp, hid, npx, C.c_float(1e-5), Cr)
+        assert rc == 0, L.ira_last_error(h)
+        rc = L.ira_op_pw_kres_ex(h, ptr(xb), 1, 2, Cp, ptr(W1d), ptr(b1d), ptr(hbuf), hid, hid, hid // 32, 1, npx, C.c_float(1e-5), Cr, 1)
+        assert rc == 0, L.ira_last_error(h)
+        rc = L.ira_op_pw_nres(h, ptr(hbuf), hid, None, 0, 0, ptr(W2d), 0, ptr(b2d), ptr(xb), ptr(xb), Cp, Cp // 32, 1, npx)
+        assert rc == 0, L.ira_last_error(h)
+    finally:
+        if planes == 1:
+            be.close()
+    assert torch.equal(xa, xb)
+    xr = x[:, :Cr]
+    mu = xr.mean(-1, keepdim=True); var = xr.var(-1, keepdim=True, unbiased=False)
+    n = r16((xr - mu) / torch.sqrt(var + 1e-5))
+    Wa, Wb = (r16(W1), r16(W2)) if planes == 1 else (W1, W2)
+    hd = r16(F.gelu((n.double() @ Wa[:, :Cr].double().t()).float() + b1))
+    ref = x.clone(); ref[:, :Cr] += ((hd.double() @ Wb[:Cr].double().t()).float() + b2[:Cr])
+    close(xa.cpu()[:, :Cr], ref[:, :Cr], 1e-3, 1e-3)        # fp16 rounding of the hidden values can flip by one unit next to ties
+
+
 @pytest.mark.parametrize('Hp,T,H,W,with_bias', [(64, 2, 6, 9, False), (128, 1, 4, 24, False), (32, 1, 2, 3, False),
                                                 (1024, 1, 5, 10, True),      # k_dwconv_gate_row: two chunks of 64 channel octets, rows not a multiple of 4
                                                 (512, 2, 9, 37, True)])       # ragged last 4-pixel step, several row segments per band
