@@ -49,8 +49,8 @@ constexpr int NBORDER = 2 * PW + 2 * TH;                                    // 8
 constexpr int HPS = 40;                                                     // hp row stride in halfs: 16 (x1) + 16 (x2) + 8 pad
 constexpr size_t HP_BYTES = (size_t)PHW * HPS * 2;                          // 27 200 B
 constexpr size_t G_BYTES = (size_t)4 * 2 * 64 * 16;                         // [row pair][row][lane] half8: 8 192 B
-constexpr int NTAB = 1024;
-constexpr float TAB_RANGE = 6.0f;
+constexpr int NTAB = PHI_NTAB;
+constexpr float TAB_RANGE = PHI_RANGE;
 constexpr size_t TAB_BYTES = NTAB * 8;
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));

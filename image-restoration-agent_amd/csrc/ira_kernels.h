@@ -76,6 +76,10 @@ hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);
 
 // ira_ffn2.hip: the (Phi, slope) table of the GELU look-up, 1024 entries of float2 over [0, 6), one copy per device
+// Phi table (one device copy per GPU, filled on first use): tab[i] = (Phi(i h), Phi((i + 1) h) - Phi(i h)), h = PHI_RANGE / PHI_NTAB;
+// gelu(a) = |a| Phi(|a|) + min(a, 0) with Phi interpolated linearly (error < 1.1e-6 |a|, far below the fp16 rounding of what it feeds)
+constexpr int PHI_NTAB = 1024;
+constexpr float PHI_RANGE = 6.0f;
 hipError_t phi_table(const float2** out);
 bool ffn2_supported(int C, int Hp);
 hipError_t launch_ffn2(hipStream_t st, const float* x, float* x_out, const void* v, const void* M, long m_tile_stride, const float* wo_b,

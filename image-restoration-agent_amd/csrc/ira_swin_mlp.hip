@@ -19,25 +19,41 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
+
+#ifdef IRA_MLP_STAMPS                                                        // timeline build (tools/mlp_stamps.py), never the product library
+__device__ unsigned long long g_mlp_stamps[160];
+#define MLP_STAMP(i) do { if (blockIdx.x == 777 && threadIdx.x == 0 && (i) < 160) g_mlp_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ira_debug_mlp_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * (n < 160 ? n : 160));
+}
+#define MLP_RSTAMP(i) do { if (blockIdx.x == 777 && threadIdx.x == 0) g_mlp_stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
+#else
+#define MLP_RSTAMP(i) do {} while (0)
+#define MLP_STAMP(i) do {} while (0)
+#endif
 
 namespace ira {
 
 namespace {
 
+typedef f16 half2 __attribute__((ext_vector_type(2)));
+
 constexpr int MLP_KS = 16;      // fc1 k-steps: 256 padded input channels
 constexpr int MLP_NB2 = 8;      // fc2 output row blocks: 256 padded output channels
-constexpr int MLP_NW = 8;
 
 // DBG (IRA_SWIN_MLP_DBG, measurement only, wrong results): 1 no GELU, 2 fc1 only, 3 fc2 + GELU only, 4 prologue + epilogue, 5 staging + barriers only
-template <bool LO, int DBG = 0>
-__global__ __launch_bounds__(64 * MLP_NW, 2) void k_swin_mlp(float* __restrict__ x, const f16* __restrict__ W1, const float* __restrict__ b1,
-                                                             const f16* __restrict__ W2, const float* __restrict__ b2, int NB1, long npx,
-                                                             float eps, int ln_n) {
-    constexpr int KS = MLP_KS, NB2 = MLP_NB2, NW = MLP_NW, K = KS * 16;
+template <bool LO, int NW, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, const f16* __restrict__ W1, const float* __restrict__ b1,
+                                                         const f16* __restrict__ W2, const float* __restrict__ b2, const float2* __restrict__ phi,
+                                                         int NB1, long npx, float eps, int ln_n) {
+    constexpr int KS = MLP_KS, NB2 = MLP_NB2, K = KS * 16;
     constexpr int NPL = LO ? 2 : 1;
-    constexpr int F1 = NPL * KS, F2 = NPL * 2 * NB2, FS = F1 + F2;          // 1 KB fragments per chunk: fc1 [plane][k-step], fc2 [k-step][plane][row block]
+    constexpr int F1 = NPL * KS, F2 = NPL * 2 * NB2, FS = F1 + F2;          // 1 KB fragments per stage: fc1 [plane][k-step], fc2 [k-step][plane][row block]
     constexpr int WBUF = FS * 1024, BBUF = 256;
+    static_assert(PHI_NTAB * 8 == 8192, "the table is moved as eight 1 KB pieces");
     constexpr int RS = 64 * 4 + 16;
+    constexpr int PF = 4;                                                     // weight fragments requested from LDS ahead of the MFMA that uses them
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -45,6 +61,79 @@ __global__ __launch_bounds__(64 * MLP_NW, 2) void k_swin_mlp(float* __restrict__
     const int nvalid = p0 < npx ? (int)((npx - p0) < 32 ? (npx - p0) : 32) : 0;
     const long px = (p0 + r < npx) ? p0 + r : npx - 1;
     const int KT2 = 2 * NB1;                                                  // fc2 k-steps (hidden / 16)
+
+    MLP_STAMP(0);
+    MLP_RSTAMP(5);
+    const char* w1lane = (const char*)W1 + lane * 16;
+    const char* w2lane = (const char*)W2 + lane * 16;
+    const long lo1 = (long)NB1 * KS * 1024, lo2 = (long)NB2 * KT2 * 1024;    // bytes between the planes
+    // stage c = what trip c of the loop below consumes: fc1 row block c (c < NB1), its 32 biases, and the fc2 slab of chunk c - 1 (c >= 1)
+    auto stage = [&](int c, int buf) {
+        char* dst = smem + buf * (WBUF + BBUF);
+#pragma unroll
+        for (int i = 0; i < (FS + NW - 1) / NW; ++i) {
+            const int f = wave + NW * i;
+            if (f < F1) {
+                if (c < NB1) {
+                    const int plane = f / KS, s = f - plane * KS;
+                    const char* src = w1lane + (plane ? lo1 : 0) + ((long)c * KS + s) * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+                }
+            } else if (f < FS) {
+                if (c >= 1) {
+                    const int g = f - F1, ks = g / (NPL * NB2), rem = g - ks * NPL * NB2, plane = rem / NB2, nb = rem - plane * NB2;
+                    const char* src = w2lane + (plane ? lo2 : 0) + ((long)nb * KT2 + 2 * (c - 1) + ks) * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+                }
+            }
+        }
+        if (wave == NW - 1 && c < NB1) {                                     // 64 floats moved, 32 used: the index is clamped to the array
+            const int idx = (32 * c + lane < 32 * NB1) ? 32 * c + lane : 32 * NB1 - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1 + idx),
+                                             (__attribute__((address_space(3))) void*)(dst + WBUF), 4, 0, 0);
+        }
+    };
+    // DMA pieces of stage cn without conditions, for the steady-state trips (2 <= cn <= NB1; the fc1 block of stage NB1 does not exist:
+    // block NB1 - 1 is fetched again and never read).  Piece i of wave w is fragment f = w + NW i of the stage; the two source bases of
+    // the trip go through an empty asm so that the eight piece addresses are one add each from them, not sixteen hoisted registers.
+    static_assert(FS % NW == 0 && F1 % NW == 0 && KS % NW == 0 && NB2 % NW == 0, "every wave issues the same pieces, of the same kinds");
+    constexpr int NPC = FS / NW;                                             // DMA pieces per wave and stage
+    static_assert(NPC == KS / 2, "one DMA piece rides behind each k-step of the second half of fc1");
+    unsigned dma_l16 = 0;                                                    // lane * 16, the only vector part of a piece address (SGPR base + 32-bit offset form)
+    auto dma_bases = [&]() {
+        dma_l16 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) << 4;
+        asm volatile("" : "+v"(dma_l16));                                    // opaque: no per-piece address pair is precomputed and kept (spilled) across trips
+    };
+    auto dma_piece = [&](int cn, int i) {
+        char* dst = smem + (cn & 1) * (WBUF + BBUF) + (wave + NW * i) * 1024;
+        const char* src;
+        if (i < F1 / NW) {
+            const int plane = i / (KS / NW), sp = NW * (i % (KS / NW));      // k-step = wave + sp
+            const int blk = cn < NB1 ? cn : NB1 - 1;
+            src = (const char*)W1 + (plane ? lo1 : 0) + ((long)blk * KS + wave + sp) * 1024;
+        } else {
+            const int g0 = NW * (i - F1 / NW);                               // fragment g0 + wave of the fc2 part: [k-step][plane][row block]
+            const int ks = g0 / (NPL * NB2), rem0 = g0 % (NPL * NB2), plane = rem0 / NB2, nb0 = rem0 % NB2;   // row block = nb0 + wave
+            src = (const char*)W2 + (plane ? lo2 : 0) + ((long)(nb0 + wave) * KT2 + 2 * (cn - 1) + ks) * 1024;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + dma_l16), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto bias_piece_all = [&](int cn) {                                      // every wave moves the same 256 bytes to the same place: no branch in the trip
+        const int blk = cn < NB1 ? cn : NB1 - 1;
+        const int idx = (32 * blk + lane < 32 * NB1) ? 32 * blk + lane : 32 * NB1 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1 + idx),
+                                         (__attribute__((address_space(3))) void*)(smem + (cn & 1) * (WBUF + BBUF) + WBUF), 4, 0, 0);
+    };
+    // first the requests that do not depend on the tokens: stage 0 by DMA and the Phi table (8 KB; a separate LDS object that no DMA ever
+    // writes: its look-ups then need no vmcnt wait - inside the dynamic array, or filled by LDS-DMA, every table read waited for vmcnt(0),
+    // i.e. for all the DMA pieces in flight); they travel while the tokens are loaded and normalised
+    stage(0, 0);
+    __shared__ float2 tab[PHI_NTAB];
+    f32x4 treg[512 / (64 * NW)];
+#pragma unroll
+    for (int i = 0; i < 512 / (64 * NW); ++i) treg[i] = ((const f32x4*)phi)[threadIdx.x + 64 * NW * i];
 
     // LayerNorm (the arithmetic of k_pw_wide / k_pw_kres_lds) -> fp16 B fragments of the wave's 32 tokens
     half8 b[KS];
@@ -82,91 +171,144 @@ __global__ __launch_bounds__(64 * MLP_NW, 2) void k_swin_mlp(float* __restrict__
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc2[nb][8 * u + e] = b2[32 * nb + 16 * u + 8 * h + e];
 
-    const char* w1lane = (const char*)W1 + lane * 16;
-    const char* w2lane = (const char*)W2 + lane * 16;
-    const long lo1 = (long)NB1 * KS * 1024, lo2 = (long)NB2 * KT2 * 1024;    // bytes between the planes
-    auto stage = [&](int c, int buf) {
-        char* dst = smem + buf * (WBUF + BBUF);
+    MLP_STAMP(1);
 #pragma unroll
-        for (int i = 0; i < (FS + NW - 1) / NW; ++i) {
-            const int f = wave + NW * i;
-            if (f < FS) {
-                const char* src;
-                if (f < F1) {
-                    const int plane = f / KS, s = f - plane * KS;
-                    src = w1lane + (plane ? lo1 : 0) + ((long)c * KS + s) * 1024;
-                } else {
-                    const int g = f - F1, ks = g / (NPL * NB2), rem = g - ks * NPL * NB2, plane = rem / NB2, nb = rem - plane * NB2;
-                    src = w2lane + (plane ? lo2 : 0) + ((long)nb * KT2 + 2 * c + ks) * 1024;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
-            }
-        }
-        if (wave == NW - 1) {                                                // the chunk's 32 fc1 biases (64 floats moved, the array is clamped)
-            const int idx = (32 * c + lane < 32 * NB1) ? 32 * c + lane : 32 * NB1 - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1 + idx),
-                                             (__attribute__((address_space(3))) void*)(dst + WBUF), 4, 0, 0);
-        }
-    };
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < 512 / (64 * NW); ++i) ((f32x4*)tab)[threadIdx.x + 64 * NW * i] = treg[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    MLP_STAMP(2);
 
-    for (int c = 0; c < (DBG == 4 ? 0 : NB1); ++c) {
+    // Trip c: fc1 of chunk c (hidden channels 32c .. 32c+31 of the wave's tokens) into acc_n, while the VALU turns chunk c-1's fc1 result
+    // (acc_o) into fp16 GELU values - the B fragments of fc2 k-steps 2(c-1), 2(c-1)+1 - and then those 2 x 8 fc2 MFMAs.  NB1 + 1 trips.
+    f32x16 acc_o = zero16();
+    auto trip = [&](int c, auto FC1c, auto FC2c) {
+        constexpr bool fc1 = decltype(FC1c)::value && DBG != 3 && DBG != 5, has1 = decltype(FC1c)::value;
+        constexpr bool has2 = decltype(FC2c)::value, fc2 = has2 && DBG != 2 && DBG != 5;
         const char* cur = smem + (c & 1) * (WBUF + BBUF);
-        const half8* w1 = (const half8*)cur;
-        const half8* w2 = (const half8*)(cur + F1 * 1024);
-        if (c + 1 < NB1) stage(c + 1, (c + 1) & 1);
-        // fc1 row block c: hidden channels 32c .. 32c+31 of the wave's 32 tokens
-        f32x16 acc1;
-        {
+        const half8* w1 = (const half8*)cur + lane;
+        const half8* w2 = (const half8*)(cur + F1 * 1024) + lane;
+        constexpr bool steady = decltype(FC1c)::value && decltype(FC2c)::value && DBG == 0;   // DMA pieces ride between the fc1 MFMAs
+        MLP_STAMP(8 + 8 * c);
+        if constexpr (!steady) { if (c + 1 <= NB1) stage(c + 1, (c + 1) & 1); }
+        MLP_STAMP(8 + 8 * c + 1);
+        f32x16 acc_n = zero16();
+        if constexpr (has1) {
             const float* bl = (const float*)(cur + WBUF) + 8 * h;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const f32x4 lo = *(const f32x4*)(bl + 16 * u), hi = *(const f32x4*)(bl + 16 * u + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc1[8 * u + e] = lo[e]; acc1[8 * u + 4 + e] = hi[e]; }
+                for (int e = 0; e < 4; ++e) { acc_n[8 * u + e] = lo[e]; acc_n[8 * u + 4 + e] = hi[e]; }
             }
         }
-        if constexpr (DBG != 3 && DBG != 5)
+        half2 hp[8];                                                         // GELU(acc_o) as fp16 pairs: the B fragments of fc2 k-steps 2(c-1), 2(c-1)+1
+        // GELU through the Phi table (as the fused GDFN kernel): gelu(a) = |a| Phi(|a|) + min(a, 0).  The look-up of pair j (index, fraction,
+        // ds_read_b64 of (Phi, slope)) is issued one MFMA group before the arithmetic that uses it.
+        float gfr[2]; float2 gte[2];
+        auto gelu_lookup = [&](int j) {
+            if constexpr (DBG == 1 || DBG == 5) return;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s * 64 + lane], b[s], acc1, 0, 0, 0);
-            if constexpr (LO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[(KS + s) * 64 + lane], b[s], acc1, 0, 0, 0);
+            for (int e = 0; e < 2; ++e) {
+                const float tt = fminf(fabsf(acc_o[2 * j + e]) * ((float)PHI_NTAB / PHI_RANGE), (float)PHI_NTAB - 0.004f);
+                gfr[e] = __builtin_amdgcn_fractf(tt);
+                gte[e] = tab[(int)tt];
+            }
+        };
+        auto gelu_finish = [&](int j) {
+            float g[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a = acc_o[2 * j + e];
+                g[e] = (DBG == 1 || DBG == 5) ? a : fmaf(fabsf(a), fmaf(gfr[e], gte[e].y, gte[e].x), fminf(a, 0.f));
+            }
+            hp[j] = half2{(f16)g[0], (f16)g[1]};
+            asm volatile("" : "+v"(hp[j]));                                  // the pair is computed HERE (in the MFMA shadow it was written into), not sunk below the loop
+        };
+        if constexpr (fc1) {
+            constexpr int PF = 3;                                            // (register budget: 256 with b, acc2, acc_o, acc_n, the GELU pairs live)
+            half8 a[PF];                                                     // order (k-step, plane): the hi / lo order of k_pw_wide
+#pragma unroll
+            for (int q = 0; q < PF; ++q) a[q] = w1[((q % NPL) * KS + q / NPL) * 64];
+            if constexpr (steady) dma_bases();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {                                   // per k-step: its MFMA(s), then in their shadow a DMA piece (even s) or a GELU pair (odd s)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const int q = s * NPL + pl;
+                    acc_n = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % PF], b[s], acc_n, 0, 0, 0);
+                    if (q + PF < F1) a[q % PF] = w1[(((q + PF) % NPL) * KS + (q + PF) / NPL) * 64];
+                }
+                // first half: GELU pair s looked up, pair s - 1 finished - the table reads happen while no DMA is in flight (the compiler
+                // puts vmcnt(0) in front of every LDS read it cannot tell from a DMA target); second half: the next stage's DMA pieces
+                if constexpr (has2) {
+                    if (s >= 1 && s <= KS / 2) gelu_finish(s - 1);
+                    if (s < KS / 2) gelu_lookup(s);
+                }
+                if constexpr (steady) {
+                    if (s == KS / 2) bias_piece_all(c + 1);
+                    if (s >= KS / 2) dma_piece(c + 1, s - KS / 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // keeps that interleaving
+            }
+        } else if constexpr (has2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gelu_lookup(j); gelu_finish(j); }
         }
-        // GELU (exact-erf form of the two-kernel path), fp16: registers 0-7 / 8-15 are the B fragments of fc2 k-steps 2c / 2c+1
         half8 hf[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int j = 0; j < 8; ++j) { hf[j >> 2][2 * (j & 3)] = hp[j][0]; hf[j >> 2][2 * (j & 3) + 1] = hp[j][1]; }
+        MLP_STAMP(8 + 8 * c + 2);
+        if constexpr (has2) {
+            if constexpr (fc2) {
+                half8 a[PF];                                                 // order (k-step, row block, plane) as k_nres_wide
+                auto off2 = [](int q) { const int ks = q / (NPL * NB2), rem = q % (NPL * NB2), nb = rem / NPL, plane = rem % NPL; return (ks * NPL * NB2 + plane * NB2 + nb) * 64; };
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hf[u][e] = (DBG == 1 || DBG == 5) ? (f16)acc1[8 * u + e] : (f16)gelu_erf(acc1[8 * u + e]);
-        if constexpr (DBG == 2 || DBG == 5) {
-            if (hf[0][0] == (f16)12345.f && hf[1][7] == (f16)-4321.f) acc2[0][0] += 1.f;   // keeps fc1 alive
-        } else
+                for (int q = 0; q < PF; ++q) a[q] = w2[off2(q)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < NB2; ++nb) {
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[(ks * NPL * NB2 + nb) * 64 + lane], hf[ks], acc2[nb], 0, 0, 0);
-                if constexpr (LO) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[(ks * NPL * NB2 + NB2 + nb) * 64 + lane], hf[ks], acc2[nb], 0, 0, 0);
+                for (int q = 0; q < F2; ++q) {
+                    const int ks = q / (NPL * NB2), nb = (q % (NPL * NB2)) / NPL;
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % PF], hf[ks], acc2[nb], 0, 0, 0);
+                    if (q + PF < F2) a[q % PF] = w2[off2(q + PF)];
+                    __builtin_amdgcn_sched_barrier(0);                       // PF reads stay in flight
+                }
+            } else {
+                if (hf[0][0] == (f16)12345.f && hf[1][7] == (f16)-4321.f) acc2[0][0] += 1.f;      // keeps fc1 / GELU alive in the measurement variants
             }
+        }
+        acc_o = acc_n;
+        MLP_STAMP(8 + 8 * c + 3);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // no store in the loop: everything outstanding is the next stage
+        MLP_STAMP(8 + 8 * c + 4);
         __builtin_amdgcn_s_barrier();
+        MLP_STAMP(8 + 8 * c + 5);
+    };
+    if constexpr (DBG != 4) {
+        trip(0, std::true_type{}, std::false_type{});
+        for (int c = 1; c < NB1; ++c) trip(c, std::true_type{}, std::true_type{});
+        trip(NB1, std::false_type{}, std::true_type{});
     }
 
+    MLP_STAMP(3);
     // epilogue: x += acc2 + b2, two row blocks (64 channels = 256 bytes per token) at a time through this wave's LDS rows
     char* tr = smem + wave * 32 * RS;
     const int piece = lane & 15, row0 = lane >> 4;
-#pragma unroll
-    for (int pr = 0; pr < NB2 / 2; ++pr) {
-        const int n0 = 64 * pr + 4 * piece;
-        f32x4 rs[8];
+    // the residual rows are requested two iterations ahead (the registers of b[], then of the accumulators already written out, hold them):
+    // one memory latency for the whole epilogue instead of one per iteration
+    f32x4 rs[NB2 / 2][8];
+    auto rs_load = [&](int pr) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row0 + 4 * i;
-            rs[i] = row < nvalid ? *(const f32x4*)(x + (p0 + row) * K + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rs[pr][i] = row < nvalid ? *(const f32x4*)(x + (p0 + row) * K + 64 * pr + 4 * piece) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    rs_load(0);
+    rs_load(1);
+#pragma unroll
+    for (int pr = 0; pr < NB2 / 2; ++pr) {
+        const int n0 = 64 * pr + 4 * piece;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -183,11 +325,14 @@ __global__ __launch_bounds__(64 * MLP_NW, 2) void k_swin_mlp(float* __restrict__
         for (int i = 0; i < 8; ++i) {
             const int row = row0 + 4 * i;
             f32x4 v = *(const f32x4*)(tr + row * RS + piece * 16);
-            v += rs[i];                                                      // residual last, as in the two-kernel path
+            v += rs[pr][i];                                                  // residual last, as in the two-kernel path
             if (row < nvalid) *(f32x4*)(x + (p0 + row) * K + n0) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (pr + 2 < NB2 / 2) rs_load(pr + 2);
     }
+    MLP_STAMP(4);
+    MLP_RSTAMP(6);
 }
 
 int env_int_m(const char* name, int dflt) {
@@ -202,34 +347,39 @@ bool swin_mlp_supported(int Cp, int hidp, long npx) {
     return on && Cp == 256 && hidp % 32 == 0 && hidp >= 64 && hidp <= 1024 && npx >= 32768;
 }
 
+template <bool LO, int NW, int DBG>
+static hipError_t swin_mlp_launch(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int NB1, long npx, float eps,
+                                  int ln_n) {
+    const float2* phi = nullptr;
+    if (hipError_t e = phi_table(&phi); e != hipSuccess) return e;
+    constexpr int NPL = LO ? 2 : 1;
+    const dim3 grid((unsigned)((npx + 32 * NW - 1) / (32 * NW))), block(64 * NW);
+    // two stages (fc1 row block + fc2 slab + biases) or, if larger, the epilogue's transposition rows, which reuse the same LDS (the Phi table is a static 8 KB on top)
+    const size_t smem = std::max((size_t)2 * ((size_t)(NPL * MLP_KS + NPL * 2 * MLP_NB2) * 1024 + 256), (size_t)NW * 32 * (64 * 4 + 16));
+    static std::atomic<uint64_t> done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<LO, NW, DBG>, smem, done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_swin_mlp<LO, NW, DBG>), grid, block, smem, st, x, (const f16*)W1, b1, (const f16*)W2, b2, phi, NB1, npx, eps, ln_n);
+    return hipGetLastError();
+}
+
 hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int Cp, int hidp, long npx,
                            float eps, int ln_n, int planes) {
     if (!swin_mlp_supported(Cp, hidp, npx) || !b1 || !b2) return hipErrorInvalidValue;
     const int NB1 = hidp / 32;
-    const dim3 grid((unsigned)((npx + 32 * MLP_NW - 1) / (32 * MLP_NW))), block(64 * MLP_NW);
-    auto smem_of = [](int npl) { return std::max((size_t)2 * ((size_t)(npl * MLP_KS + npl * 2 * MLP_NB2) * 1024 + 256), (size_t)MLP_NW * 32 * (64 * 4 + 16)); };
-    static std::atomic<uint64_t> d1{0}, d2{0};
-    static const int dbg = env_int_m("IRA_SWIN_MLP_DBG", 0);
-    if (planes == 1 && dbg >= 1 && dbg <= 5) {
-        const size_t smem = smem_of(1);
-        const void* fn = dbg == 1 ? (const void*)k_swin_mlp<false, 1> : dbg == 2 ? (const void*)k_swin_mlp<false, 2> : dbg == 3 ? (const void*)k_swin_mlp<false, 3>
-                       : dbg == 4 ? (const void*)k_swin_mlp<false, 4> : (const void*)k_swin_mlp<false, 5>;
-        static std::atomic<uint64_t> dd{0};
-        if (hipError_t e = ensure_dynamic_lds(fn, smem, dd); e != hipSuccess) return e;
-        const f16 *w1 = (const f16*)W1, *w2 = (const f16*)W2;
-        void* args[] = {&x, &w1, &b1, &w2, &b2, (void*)&NB1, &npx, &eps, &ln_n};
-        return hipLaunchKernel(fn, grid, block, args, smem, st);
-    }
+    // plain fp16 weights: 64.5 KB of LDS per workgroup of FOUR waves, two workgroups per CU (their load / MFMA / store phases overlap);
+    // hi + lo planes: 128.5 KB, one workgroup of eight waves
     if (planes == 1) {
-        const size_t smem = smem_of(1);
-        if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<false>, smem, d1); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_swin_mlp<false>, grid, block, smem, st, x, (const f16*)W1, b1, (const f16*)W2, b2, NB1, npx, eps, ln_n);
-    } else {
-        const size_t smem = smem_of(2);
-        if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<true>, smem, d2); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_swin_mlp<true>, grid, block, smem, st, x, (const f16*)W1, b1, (const f16*)W2, b2, NB1, npx, eps, ln_n);
+        static const int dbg = env_int_m("IRA_SWIN_MLP_DBG", 0);
+        switch (dbg) {
+            case 1: return swin_mlp_launch<false, 4, 1>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+            case 2: return swin_mlp_launch<false, 4, 2>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+            case 3: return swin_mlp_launch<false, 4, 3>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+            case 4: return swin_mlp_launch<false, 4, 4>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+            case 5: return swin_mlp_launch<false, 4, 5>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+            default: return swin_mlp_launch<false, 4, 0>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+        }
     }
-    return hipGetLastError();
+    return swin_mlp_launch<true, 8, 0>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
 }
 
 }  // namespace ira

@@ -250,7 +250,7 @@ def test_pw_nres_hi_plane_only(ctx, K, N):
 @pytest.mark.parametrize('planes,npx', [(2, 32768 + 77), (1, 40000)])
 def test_swin_mlp_fused(ctx, planes, npx):
     """k_swin_mlp (network_swinir.py:274-277, Mlp :14-30): x += fc2(GELU(fc1(LN(x)))) with the hidden activations on chip, against
-    (a) the two kernels it replaces through an fp16 hidden tensor - bit for bit - and (b) a torch fp32 statement with the same rounding
+    (a) the two kernels it replaces through an fp16 hidden tensor and (b) a torch fp32 statement with the same rounding
     points (fp16 LayerNorm output, fp16 hidden).  Ragged last workgroup; 240 real of 256 channels as SwinIR-L."""
     g = torch.Generator().manual_seed(planes * 7 + 1)
     Cp, Cr, hid = 256, 240, 480
@@ -274,7 +274,9 @@ def test_swin_mlp_fused(ctx, planes, npx):
     finally:
         if planes == 1:
             be.close()
-    assert torch.equal(xa, xb)
+    # the fused kernel takes GELU from the Phi table of the fused GDFN kernel (|error| < 1.1e-6 |a|), the two-kernel path from the erf
+    # polynomial: the fp16 hidden values differ by one unit in a few places, and with them the last bits of most outputs
+    close(xa.cpu(), xb.cpu(), 2e-4, 2e-4)
     xr = x[:, :Cr]
     mu = xr.mean(-1, keepdim=True); var = xr.var(-1, keepdim=True, unbiased=False)
     n = r16((xr - mu) / torch.sqrt(var + 1e-5))

@@ -1,8 +1,9 @@
 """A/B of the fused SwinIR MLP kernel (csrc/ira_swin_mlp.hip) against the two kernels it replaces: one SwinIR-L x4 forward of a
-seeded 264 x 264 frame (padded to 272 x 272 = 73984 tokens, above the fused kernel's 32768-token threshold) per weight-plane
-mode; prints the SHA-256 of the fp32 output.  Run once with IRA_SWIN_MLP=0 and once with IRA_SWIN_MLP=1 (the switch is read once per
-process) and compare the lines: they must be identical (same MFMA order per accumulator, same rounding points).
-usage (GPU box): IRA_SWIN_MLP=0 python tools/ab_swin_mlp.py > a.txt && IRA_SWIN_MLP=1 python tools/ab_swin_mlp.py > b.txt && cmp a.txt b.txt"""
+seeded 272 x 272 frame (73984 tokens, above the fused kernel's 32768-token threshold) per weight-plane mode; prints the SHA-256 and the
+mean of the fp32 output.  Run once with IRA_SWIN_MLP=0 and once with IRA_SWIN_MLP=1 (the switch is read once per process).  With the
+erf-polynomial GELU in both paths the two runs were bit-identical (commit edbe53c); since the fused kernel takes GELU from the Phi table
+the hashes differ and the means agree to the printed digits (tests/test_gpu_ops.py::test_swin_mlp_fused bounds the difference per element).
+usage (GPU box): IRA_SWIN_MLP=0 python tools/ab_swin_mlp.py; IRA_SWIN_MLP=1 python tools/ab_swin_mlp.py"""
 import hashlib, os, sys
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(R, 'image-restoration-agent_amd')); sys.path.insert(0, R)
