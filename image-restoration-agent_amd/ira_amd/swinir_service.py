@@ -2,7 +2,7 @@
 
 Mirrors AgentApp/model_service/super_resolution/SwinIR/model_serving.py: ``define_model`` (:43-103), ``load_model`` with its
 cache key (:105-128), ``process_image`` (:131-175: float32 HWC **BGR** in [0,1] -> uint8 HWC BGR, always-pad flip-concat, whole
-or tiled, crop, clamp, round) and the routes /health, /predict, /predict_batch (:178-334).  Image decode/encode is PIL (cv2 is
+or tiled, crop, clamp, round) and the routes /health, /predict, /predict_batch (:178-334).  PNG decode is the library's (csrc/ira_png.cpp), PNG encode tools.encode_png, other containers PIL (cv2 is
 not installed); PNG is lossless so the library does not change the pixels.
 """
 from __future__ import annotations
@@ -83,20 +83,17 @@ class SwinIRService:
 
 
 def _decode_bgr(data: bytes):
-    from PIL import Image
+    from .tools import decode_image
     try:
-        with Image.open(io.BytesIO(data)) as im:
-            rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+        rgb = decode_image(bytes(data))
     except Exception:   # noqa: BLE001
         return None
     return rgb[:, :, ::-1].astype(np.float32) / 255.          # cv2.IMREAD_COLOR order, :228-232
 
 
 def _encode_png_bgr(bgr: np.ndarray) -> bytes:
-    from PIL import Image
-    buf = io.BytesIO()
-    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(buf, format='PNG')
-    return buf.getvalue()
+    from .tools import encode_png
+    return encode_png(np.ascontiguousarray(bgr[:, :, ::-1]))
 
 
 def make_app(service: Optional[SwinIRService] = None):

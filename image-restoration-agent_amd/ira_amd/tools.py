@@ -178,13 +178,42 @@ def set_default_cache(cache: Optional[BackendCache]):
 
 
 # ------------------------------------------------------------------------------------------------
+def decode_image(data: bytes, gray: bool = False) -> np.ndarray:
+    """cv2.imdecode / cv2.imread of the reference (demo.py:40-47: IMREAD_COLOR + BGR2RGB, or IMREAD_GRAYSCALE; model_serving.py:126-134):
+    uint8 (h,w,3) RGB or, for the grey task, (h,w,1).  PNG streams are decoded by the library (csrc/ira_png.cpp); other containers (the
+    reference's demo inputs are .jpg) and the PNG variants the native decoder declines (16-bit, interlaced, 1/2/4-bit) go to PIL.  Alpha
+    is dropped and grey is replicated as IMREAD_COLOR does; RGB -> grey uses PIL's 'L' weights (19595 R + 38470 G + 7471 B + 32768) >> 16,
+    which is what this wrapper has always returned."""
+    from ._capi import IraError, decode_png
+    a = None
+    if data[:8] == b'\x89PNG\r\n\x1a\n':
+        try:
+            a = decode_png(data)
+        except IraError:
+            a = None                                     # a PNG variant left to PIL (or a broken stream: PIL raises its own error)
+    if a is None:
+        import io
+        from PIL import Image
+        with Image.open(io.BytesIO(data)) as im:
+            if gray:
+                return np.asarray(im.convert('L'), dtype=np.uint8)[:, :, None].copy()
+            return np.asarray(im.convert('RGB'), dtype=np.uint8).copy()
+    c = a.shape[2]
+    if c in (2, 4):
+        a = a[:, :, :c - 1]                              # alpha is ignored (IMREAD_COLOR / IMREAD_GRAYSCALE)
+        c -= 1
+    if gray:
+        if c == 1:
+            return np.ascontiguousarray(a)
+        r, g, b = (a[:, :, i].astype(np.uint32) for i in range(3))
+        return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)[:, :, None]
+    return np.ascontiguousarray(a) if c == 3 else np.repeat(a, 3, axis=2)
+
+
 def read_image(path, gray: bool = False) -> np.ndarray:
-    """demo.py:40-47 (cv2.imread + BGR2RGB / IMREAD_GRAYSCALE) with PIL: uint8 (h,w,3) RGB or (h,w,1)."""
-    from PIL import Image
-    with Image.open(path) as im:
-        if gray:
-            return np.asarray(im.convert('L'), dtype=np.uint8)[:, :, None].copy()
-        return np.asarray(im.convert('RGB'), dtype=np.uint8).copy()
+    """demo.py:40-47 on a file: see decode_image."""
+    with open(path, 'rb') as f:
+        return decode_image(f.read(), gray)
 
 
 def encode_png(img: np.ndarray, level: int = 1) -> bytes:

@@ -294,6 +294,15 @@ int ira_strip_restore_u8_device(ira_model_t* model, const uint8_t* frame_u8_dev,
 
 /* ------------------------------------------------------------------ measurement */
 
+/* ------------------------------------------------------------------ PNG decode (host only: no device, no handle)
+ * replaces cv2.imread / cv2.imdecode in front of the path (AgenticIR/executor/.../Restormer/demo.py:40-44; AgentApp model_serving.py:126-134).
+ * 8 bits per sample, colour types 0 / 2 / 3 / 4 / 6, not interlaced; chunk CRCs and the zlib Adler-32 are checked.  ira_png_info reads the
+ * header: channels = 1 grey, 2 grey + alpha, 3 RGB (also for palette images, which are expanded), 4 RGBA.  ira_png_decode writes the
+ * h x w x channels raster (row-major, RGB order as stored) into out.  Anything else (16-bit, Adam7, 1/2/4-bit) -> IRA_ERR_ARG with the reason
+ * in ira_last_error(NULL); the Python wrapper then hands the file to PIL. */
+int ira_png_info(const uint8_t* png, size_t len, int* h, int* w, int* channels);
+int ira_png_decode(const uint8_t* png, size_t len, uint8_t* out, size_t out_bytes);
+
 /* ------------------------------------------------------------------ brightening tools (no weights, no handle)
  * replaces BrighteningTool._invoke between cv2.imread and cv2.imwrite (AgenticIR/executor/brightening/__init__.py:19-31):
  * cv2.cvtColor(BGR2HSV) -> _update_v(V) -> cv2.cvtColor(HSV2BGR), 8-bit, on RGB-ordered pixels (H, S, V do not depend on the channel order).
