@@ -52,7 +52,9 @@ int walk(const uint8_t* png, size_t len, PngInfo& info, Pieces* idat, uint8_t (*
             if (memcmp(tag, "IHDR", 4) != 0 || n != 13) return gfail(IRA_ERR_ARG, "png: first chunk is not IHDR");
             info.w = be32(data); info.h = be32(data + 4);
             info.depth = data[8]; info.ctype = data[9]; info.interlace = data[12];
-            if (info.w == 0 || info.h == 0 || info.w > (1u << 24) || info.h > (1u << 24)) return gfail(IRA_ERR_ARG, "png: bad size %u x %u", info.w, info.h);
+            // a header is untrusted input: the caller allocates h * w * channels bytes on its word (2^31 bytes = a 23k x 23k RGBA frame)
+            if (info.w == 0 || info.h == 0 || info.w > (1u << 20) || info.h > (1u << 20) || (uint64_t)info.w * info.h * 4 > (1ull << 31))
+                return gfail(IRA_ERR_ARG, "png: size %u x %u is zero or beyond the 2 GiB raster limit", info.w, info.h);
             if (data[10] != 0 || data[11] != 0) return gfail(IRA_ERR_ARG, "png: unknown compression / filter method");
             if (info.depth != 8) return gfail(IRA_ERR_ARG, "png: %d bits per sample (only 8 is decoded natively)", info.depth);
             if (info.interlace != 0) return gfail(IRA_ERR_ARG, "png: Adam7 interlacing is not decoded natively");

@@ -153,6 +153,50 @@ def test_declined_and_broken_streams():
     long_ = b'\x89PNG\r\n\x1a\n' + _chunk(b'IHDR', ihdr) + _chunk(b'IDAT', zlib.compress(b'\0' * 4000)) + _chunk(b'IEND', b'')
     with pytest.raises(IraError, match='inflates to|inflate failed'):
         decode_png(long_)
+    huge = b'\x89PNG\r\n\x1a\n' + _chunk(b'IHDR', struct.pack('>IIBBBBB', 1 << 19, 1 << 19, 8, 6, 0, 0, 0)) + _chunk(b'IDAT', zlib.compress(b'\0')) + _chunk(b'IEND', b'')
+    with pytest.raises(IraError, match='raster limit'):
+        decode_png(huge)
     badf = b'\x89PNG\r\n\x1a\n' + _chunk(b'IHDR', ihdr) + _chunk(b'IDAT', zlib.compress(b'\7' * (12 * 28))) + _chunk(b'IEND', b'')
     with pytest.raises(IraError, match='filter type 7'):
         decode_png(badf)
+
+
+def test_mutated_streams_never_crash():
+    """a parser of untrusted bytes: 400 random mutations (byte flips with the CRC repaired so that the damage reaches the inflater and the
+    filters, truncations, length-field edits) of valid streams either decode to a raster of the announced size or raise IraError"""
+    rng = np.random.default_rng(7)
+    seeds = [_pil_png(_photo(19, 23, c, c), m) for m, c in (('L', 1), ('LA', 2), ('RGB', 3), ('RGBA', 4))]
+    pal = io.BytesIO(); Image.fromarray(_photo(19, 23, 3, 9), 'RGB').quantize(colors=11).save(pal, format='PNG'); seeds.append(pal.getvalue())
+
+    def refix(b):
+        out, off = bytearray(b[:8]), 8
+        while off + 12 <= len(b):
+            n = struct.unpack('>I', b[off:off + 4])[0]
+            if off + 12 + n > len(b):
+                out += b[off:]; return bytes(out)
+            tag, data = b[off + 4:off + 8], b[off + 8:off + 8 + n]
+            out += _chunk(bytes(tag), bytes(data)); off += 12 + n
+        return bytes(out + b[off:])
+    ok = bad = 0
+    for i in range(400):
+        b = bytearray(seeds[i % len(seeds)])
+        kind = i % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(8, len(b)))] ^= int(rng.integers(1, 256))
+            data = refix(bytes(b))
+        elif kind == 1:
+            data = bytes(b[:int(rng.integers(0, len(b)))])
+        elif kind == 2:
+            pos = int(rng.integers(8, len(b) - 4)); b[pos:pos + 4] = struct.pack('>I', int(rng.integers(0, 1 << 32)))
+            data = bytes(b)
+        else:
+            b[int(rng.integers(8, len(b)))] ^= int(rng.integers(1, 256))
+            data = bytes(b)
+        try:
+            a = decode_png(data)
+            assert a.ndim == 3 and a.dtype == np.uint8
+            ok += 1
+        except IraError:
+            bad += 1
+    assert ok + bad == 400 and bad > 100
