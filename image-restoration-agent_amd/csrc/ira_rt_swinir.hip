@@ -184,8 +184,16 @@ int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float
             const int shift = (k % 2 == 0) ? 0 : ws / 2;                                                             // :385-386
             RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0, m->w_planes));
             RUN(m, k_[1], ira::launch_swin_attn(st, m->sw_qkv, b.bias_tab, m->sw_att, T, Hp, Wp, heads, ws, shift));
+            static const bool proj_fused = [] { const char* v = getenv("IRA_SWIN_PROJ_MLP"); return !(v && *v == '0'); }();
+            const bool mlp1 = ira::swin_mlp_supported(g.Cp, g.hidp, (long)T * P);
+            if (mlp1 && proj_fused && Kh == g.Cp && b.proj_b) {            // proj + residual + LN + fc1 + GELU + fc2 + residual: the second half of the block in one kernel
+                char km[64];
+                if (m->profile) snprintf(km, sizeof km, "swin_proj_mlp_fused|C%d|%dx%d|T%d", g.C, Hp, Wp, T); else km[0] = 0;
+                RUN(m, km, ira::launch_swin_mlp(st, x, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, g.Cp, g.hidp, (long)T * P, 1e-5f, g.C, m->w_planes, m->sw_att, b.proj_w, b.proj_b));
+                continue;
+            }
             RUN(m, k_[2], ira::launch_pw_nres(st, m->sw_att, Kh, nullptr, 0, false, b.proj_w, 0, b.proj_b, x, x, g.Cp, g.Cp / 32, T, P, m->w_planes));
-            if (ira::swin_mlp_supported(g.Cp, g.hidp, (long)T * P)) {      // LN + fc1 + GELU + fc2 + residual in one kernel: the hidden tensor never exists
+            if (mlp1) {      // LN + fc1 + GELU + fc2 + residual in one kernel: the hidden tensor never exists
                 char km[64];
                 if (m->profile) snprintf(km, sizeof km, "swin_mlp_fused|C%d|%dx%d|T%d", g.C, Hp, Wp, T); else km[0] = 0;
                 RUN(m, km, ira::launch_swin_mlp(st, x, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, g.Cp, g.hidp, (long)T * P, 1e-5f, g.C, m->w_planes));

@@ -894,6 +894,16 @@ int ira_op_swin_mlp(ira_model_t* m, float* x, const void* W1, const float* b1, c
     OP_BODY(m, "op", ira::launch_swin_mlp(m->st, x, W1, b1, W2, b2, Cp, hidp, npx, eps, ln_n, m->w_planes));
 }
 
+int ira_op_swin_proj_mlp(ira_model_t* m, float* x, const void* attn, const void* Wp, const float* bp, const void* W1, const float* b1, const void* W2,
+                         const float* b2, int Cp, int hidp, long npx, float eps, int ln_n) {
+    if (!m) return gfail(IRA_ERR_ARG, "ira_op_swin_proj_mlp: model is NULL");
+    if (!ira::swin_mlp_supported(Cp, hidp, npx) || !b1 || !b2 || !attn || !Wp || !bp) {
+        m->err = "ira_op_swin_proj_mlp: needs Cp == 256, hidp a multiple of 32 in [64, 1024], npx >= 32768, attn / W_p and all three biases (and IRA_SWIN_MLP != 0)";
+        return IRA_ERR_ARG;
+    }
+    OP_BODY(m, "op", ira::launch_swin_mlp(m->st, x, W1, b1, W2, b2, Cp, hidp, npx, eps, ln_n, m->w_planes, attn, Wp, bp));
+}
+
 int ira_op_dwconv_qkv(ira_model_t* m, const void* in, const float* w, const float* bias, void* qk, void* v, int T,
                       int H, int W, int C) {
     OP_BODY(m, "op", ira::launch_dwconv_qkv(m->st, in, w, bias, qk, v, T, H, W, C));

@@ -43,9 +43,13 @@ constexpr int MLP_KS = 16;      // fc1 k-steps: 256 padded input channels
 constexpr int MLP_NB2 = 8;      // fc2 output row blocks: 256 padded output channels
 
 // DBG (IRA_SWIN_MLP_DBG, measurement only, wrong results): 1 no GELU, 2 fc1 only, 3 fc2 + GELU only, 4 prologue + epilogue, 5 staging + barriers only
-template <bool LO, int NW, int DBG = 0>
+// PROJ: the attention projection + residual in front (network_swinir.py:263-271 after the window attention):  x += W_p attn + b_p  first, with
+// the arithmetic of k_nres_wide<8, 8, 4> (bias in the accumulators, k-step-major MFMA order, residual last); x is written back once (the
+// epilogue's residual) and normalised from the accumulators, whose layout is the B-fragment layout fc1 wants.
+template <bool LO, int NW, bool PROJ, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, const f16* __restrict__ W1, const float* __restrict__ b1,
                                                          const f16* __restrict__ W2, const float* __restrict__ b2, const float2* __restrict__ phi,
+                                                         const f16* __restrict__ attn, const f16* __restrict__ Wp, const float* __restrict__ bp,
                                                          int NB1, long npx, float eps, int ln_n) {
     constexpr int KS = MLP_KS, NB2 = MLP_NB2, K = KS * 16;
     constexpr int NPL = LO ? 2 : 1;
@@ -129,15 +133,101 @@ __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, 
     // first the requests that do not depend on the tokens: stage 0 by DMA and the Phi table (8 KB; a separate LDS object that no DMA ever
     // writes: its look-ups then need no vmcnt wait - inside the dynamic array, or filled by LDS-DMA, every table read waited for vmcnt(0),
     // i.e. for all the DMA pieces in flight); they travel while the tokens are loaded and normalised
-    stage(0, 0);
+    if constexpr (!PROJ) stage(0, 0);
     __shared__ float2 tab[PHI_NTAB];
     f32x4 treg[512 / (64 * NW)];
 #pragma unroll
     for (int i = 0; i < 512 / (64 * NW); ++i) treg[i] = ((const f32x4*)phi)[threadIdx.x + 64 * NW * i];
 
-    // LayerNorm (the arithmetic of k_pw_wide / k_pw_kres_lds) -> fp16 B fragments of the wave's 32 tokens
     half8 b[KS];
-    {
+    f32x16 acc2[NB2];
+    if constexpr (PROJ) {
+        // ---- x1 = x + W_p attn + b_p.  W_p travels in four stages of four k-steps, [k-step][plane][row block] like k_nres_wide, through the
+        // two stage buffers (a stage is FS fragments there too); the MLP's stage 0 is requested during the last of them
+        constexpr int KSI = 4, PST = KS / KSI;
+        static_assert(KSI * NPL * NB2 == FS, "a W_p stage fills a stage buffer exactly");
+        const char* wplane = (const char*)Wp + lane * 16;
+        const long lop = (long)NB2 * KS * 1024;
+        auto pstage = [&](int sti, int buf) {
+#pragma unroll
+            for (int i = 0; i < FS / NW; ++i) {
+                const int f = wave + NW * i;
+                const int ks = f / (NPL * NB2), rem = f - ks * NPL * NB2, plane = rem / NB2, nb = rem - plane * NB2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wplane + (plane ? lop : 0) + ((long)nb * KS + sti * KSI + ks) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * (WBUF + BBUF) + f * 1024), 16, 0, 0);
+            }
+        };
+        pstage(0, 0);
+        const f16* arow = attn + px * K + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = *(const half8*)(arow + 16 * s);
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc2[nb][8 * u + e] = bp[32 * nb + 16 * u + 8 * h + e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int sti = 0; sti < PST; ++sti) {
+            if (sti + 1 < PST) pstage(sti + 1, (sti + 1) & 1); else stage(0, 0);
+            const half8* cur = (const half8*)(smem + (sti & 1) * (WBUF + BBUF)) + lane;
+#pragma unroll
+            for (int ks = 0; ks < KSI; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NB2; ++nb) {
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(ks * NPL * NB2 + nb) * 64], b[sti * KSI + ks], acc2[nb], 0, 0, 0);
+                    if constexpr (LO) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(ks * NPL * NB2 + NB2 + nb) * 64], b[sti * KSI + ks], acc2[nb], 0, 0, 0);
+                }
+            if (sti + 1 < PST) {                                              // the last stage's successor (MLP stage 0) is awaited below, with the table
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        // residual in accumulator layout, the sums of the LayerNorm in the order of the load-based prologue, x1 back to memory
+        const float* xr = x + px * K + 8 * h;
+        float* xw = x + (p0 + r) * K + 8 * h;
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < KS / 4; ++q4) {
+            f32x4 raw[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { raw[q][0] = *(const f32x4*)(xr + 16 * (4 * q4 + q)); raw[q][1] = *(const f32x4*)(xr + 16 * (4 * q4 + q) + 4); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 4 * q4 + q, nb = s >> 1, u = s & 1;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = acc2[nb][8 * u + j] + raw[q][0][j]; hi[j] = acc2[nb][8 * u + 4 + j] + raw[q][1][j];
+                    acc2[nb][8 * u + j] = lo[j]; acc2[nb][8 * u + 4 + j] = hi[j];
+                }
+                if (r < nvalid) { *(f32x4*)(xw + 16 * s) = lo; *(f32x4*)(xw + 16 * s + 4) = hi; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += acc2[s >> 1][8 * (s & 1) + j] + acc2[s >> 1][8 * (s & 1) + 4 + j];
+        sum += __shfl_xor(sum, 32);
+        const float inv_n = 1.0f / (float)ln_n;
+        const float mu = sum * inv_n;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d0 = acc2[s >> 1][8 * (s & 1) + j] - mu, d1 = acc2[s >> 1][8 * (s & 1) + 4 + j] - mu; sq += d0 * d0 + d1 * d1; }
+        sq += __shfl_xor(sq, 32);
+        sq -= (float)(K - ln_n) * mu * mu;
+        const float rstd = 1.0f / sqrtf(sq * inv_n + eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b[s][j] = (f16)((acc2[s >> 1][8 * (s & 1) + j] - mu) * rstd); b[s][4 + j] = (f16)((acc2[s >> 1][8 * (s & 1) + 4 + j] - mu) * rstd);
+            }
+    } else {
+        // LayerNorm (the arithmetic of k_pw_wide / k_pw_kres_lds) -> fp16 B fragments of the wave's 32 tokens
         const float* src = x + px * K + 8 * h;
         f32x4 raw[KS][2];
 #pragma unroll
@@ -163,9 +253,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, 
             for (int j = 0; j < 4; ++j) { b[s][j] = (f16)((raw[s][0][j] - mu) * rstd); b[s][4 + j] = (f16)((raw[s][1][j] - mu) * rstd); }
     }
 
-    f32x16 acc2[NB2];                                                        // start from the fc2 bias, as k_nres_wide does (same summation order)
 #pragma unroll
-    for (int nb = 0; nb < NB2; ++nb)
+    for (int nb = 0; nb < NB2; ++nb)                                         // fc2 accumulators start from the fc2 bias, as k_nres_wide does (same summation order)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -347,39 +436,48 @@ bool swin_mlp_supported(int Cp, int hidp, long npx) {
     return on && Cp == 256 && hidp % 32 == 0 && hidp >= 64 && hidp <= 1024 && npx >= 32768;
 }
 
-template <bool LO, int NW, int DBG>
-static hipError_t swin_mlp_launch(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int NB1, long npx, float eps,
-                                  int ln_n) {
+struct MlpArgs {
+    float* x; const void* W1; const float* b1; const void* W2; const float* b2;
+    const void* attn; const void* Wp; const float* bp;                      // attention projection in front (PROJ), or all NULL
+    int NB1; long npx; float eps; int ln_n;
+};
+
+template <bool LO, int NW, bool PROJ, int DBG>
+static hipError_t swin_mlp_launch(hipStream_t st, const MlpArgs& a) {
     const float2* phi = nullptr;
     if (hipError_t e = phi_table(&phi); e != hipSuccess) return e;
     constexpr int NPL = LO ? 2 : 1;
-    const dim3 grid((unsigned)((npx + 32 * NW - 1) / (32 * NW))), block(64 * NW);
+    const dim3 grid((unsigned)((a.npx + 32 * NW - 1) / (32 * NW))), block(64 * NW);
     // two stages (fc1 row block + fc2 slab + biases) or, if larger, the epilogue's transposition rows, which reuse the same LDS (the Phi table is a static 8 KB on top)
     const size_t smem = std::max((size_t)2 * ((size_t)(NPL * MLP_KS + NPL * 2 * MLP_NB2) * 1024 + 256), (size_t)NW * 32 * (64 * 4 + 16));
     static std::atomic<uint64_t> done{0};
-    if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<LO, NW, DBG>, smem, done); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_swin_mlp<LO, NW, DBG>), grid, block, smem, st, x, (const f16*)W1, b1, (const f16*)W2, b2, phi, NB1, npx, eps, ln_n);
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<LO, NW, PROJ, DBG>, smem, done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_swin_mlp<LO, NW, PROJ, DBG>), grid, block, smem, st, a.x, (const f16*)a.W1, a.b1, (const f16*)a.W2, a.b2, phi, (const f16*)a.attn,
+                       (const f16*)a.Wp, a.bp, a.NB1, a.npx, a.eps, a.ln_n);
     return hipGetLastError();
 }
 
 hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int Cp, int hidp, long npx,
-                           float eps, int ln_n, int planes) {
+                           float eps, int ln_n, int planes, const void* attn, const void* Wp, const float* bp) {
     if (!swin_mlp_supported(Cp, hidp, npx) || !b1 || !b2) return hipErrorInvalidValue;
-    const int NB1 = hidp / 32;
+    const bool proj = attn != nullptr;
+    if (proj && (!Wp || !bp)) return hipErrorInvalidValue;
+    const MlpArgs a{x, W1, b1, W2, b2, attn, Wp, bp, hidp / 32, npx, eps, ln_n};
     // plain fp16 weights: 64.5 KB of LDS per workgroup of FOUR waves, two workgroups per CU (their load / MFMA / store phases overlap);
     // hi + lo planes: 128.5 KB, one workgroup of eight waves
     if (planes == 1) {
         static const int dbg = env_int_m("IRA_SWIN_MLP_DBG", 0);
-        switch (dbg) {
-            case 1: return swin_mlp_launch<false, 4, 1>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
-            case 2: return swin_mlp_launch<false, 4, 2>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
-            case 3: return swin_mlp_launch<false, 4, 3>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
-            case 4: return swin_mlp_launch<false, 4, 4>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
-            case 5: return swin_mlp_launch<false, 4, 5>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
-            default: return swin_mlp_launch<false, 4, 0>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+        if (!proj) switch (dbg) {
+            case 1: return swin_mlp_launch<false, 4, false, 1>(st, a);
+            case 2: return swin_mlp_launch<false, 4, false, 2>(st, a);
+            case 3: return swin_mlp_launch<false, 4, false, 3>(st, a);
+            case 4: return swin_mlp_launch<false, 4, false, 4>(st, a);
+            case 5: return swin_mlp_launch<false, 4, false, 5>(st, a);
+            default: return swin_mlp_launch<false, 4, false, 0>(st, a);
         }
+        return swin_mlp_launch<false, 4, true, 0>(st, a);
     }
-    return swin_mlp_launch<true, 8, 0>(st, x, W1, b1, W2, b2, NB1, npx, eps, ln_n);
+    return proj ? swin_mlp_launch<true, 8, true, 0>(st, a) : swin_mlp_launch<true, 8, false, 0>(st, a);
 }
 
 }  // namespace ira

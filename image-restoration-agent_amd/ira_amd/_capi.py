@@ -141,6 +141,7 @@ SIGNATURES = {
     'ira_op_pw_kres_ex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i]),
     'ira_png_info': (_i, [_vp, C.c_size_t, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'ira_png_decode': (_i, [_vp, C.c_size_t, _vp, C.c_size_t]),
+    'ira_op_swin_proj_mlp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, C.c_float, _i]),
     'ira_op_swin_mlp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, C.c_float, _i]),
     'ira_op_naf_tail': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     'ira_op_naf_sca': (_i, [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i]),

@@ -457,6 +457,12 @@ int ira_op_pw_kres_ex(ira_model_t* m, const void* x_dev, int in_f32, int ln_mode
 int ira_op_swin_mlp(ira_model_t* m, float* x_dev, const void* W1_f16_dev, const float* b1_dev, const void* W2_f16_dev, const float* b2_dev,
                     int Cp, int hidp, long npx, float eps, int ln_n);
 
+/* The same with the attention projection + residual in front (network_swinir.py:263-277: the whole second half of a Swin block after the window
+ * attention):  x += W_p attn + b_p;  x += fc2(GELU(fc1(LayerNorm(x)))).  attn fp16 (npx, 256) in token order, W_p [2][8][16][64][8], b_p fp32 [256].
+ * Same result, bit for bit, as ira_op_pw_nres(attn, ..., resid = x, y = x) followed by ira_op_swin_mlp. */
+int ira_op_swin_proj_mlp(ira_model_t* m, float* x_dev, const void* attn_f16_dev, const void* Wp_f16_dev, const float* bp_dev, const void* W1_f16_dev,
+                         const float* b1_dev, const void* W2_f16_dev, const float* b2_dev, int Cp, int hidp, long npx, float eps, int ln_n);
+
 /* ---- NAFNet kernels (NAFNet_arch.py:158-326)
  * Pointwise contraction on an MFMA pixel grid of T x Hg x Wg pixels, W packed like every 1x1 here
  * ([2 planes][NBtot][K/16][64][8], per image if w_tile_stride != 0), fp32 result.

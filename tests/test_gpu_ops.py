@@ -286,6 +286,42 @@ def test_swin_mlp_fused(ctx, planes, npx):
     close(xa.cpu()[:, :Cr], ref[:, :Cr], 1e-3, 1e-3)        # fp16 rounding of the hidden values can flip by one unit next to ties
 
 
+@pytest.mark.parametrize('planes,npx', [(2, 32768 + 45), (1, 36001)])
+def test_swin_proj_mlp_fused(ctx, planes, npx):
+    """k_swin_mlp<PROJ>: the second half of a Swin block (network_swinir.py:263-277) - attention projection + residual, then the MLP
+    half-block - in one kernel, against ira_op_pw_nres followed by ira_op_swin_mlp on the same buffers: bit for bit (the projection keeps
+    k_nres_wide's arithmetic, the LayerNorm sums keep the order of the load-based prologue)."""
+    g = torch.Generator().manual_seed(planes * 11 + 3)
+    Cp, Cr, hid = 256, 240, 480
+    x = torch.zeros(npx, Cp); x[:, :Cr] = torch.randn(npx, Cr, generator=g) * 1.5 + 0.3
+    att = r16(torch.randn(npx, Cp, generator=g))
+    Wp = torch.zeros(Cp, Cp); Wp[:Cr] = torch.randn(Cr, Cp, generator=g) / Cp ** 0.5
+    bp = torch.zeros(Cp); bp[:Cr] = torch.randn(Cr, generator=g) * 0.1
+    W1 = torch.zeros(hid, Cp); W1[:, :Cr] = torch.randn(hid, Cr, generator=g) / Cr ** 0.5
+    W2 = torch.zeros(Cp, hid); W2[:Cr] = torch.randn(Cr, hid, generator=g) / hid ** 0.5
+    b1 = torch.randn(hid, generator=g) * 0.1
+    b2 = torch.zeros(Cp); b2[:Cr] = torch.randn(Cr, generator=g) * 0.1
+    Wpd, W1d, W2d, bpd, b1d, b2d, ad = dev(split16(Wp)), dev(split16(W1)), dev(split16(W2)), dev(bp), dev(b1), dev(b2), dev(att.half())
+    xa, xb = dev(x), dev(x)
+    be = ctx if planes == 2 else _hi_plane_ctx()
+    try:
+        L, h = be._lib, be.handle
+        rc = L.ira_op_swin_proj_mlp(h, ptr(xa), ptr(ad), ptr(Wpd), ptr(bpd), ptr(W1d), ptr(b1d), ptr(W2d), ptr(b2d), Cp, hid, npx, C.c_float(1e-5), Cr)
+        assert rc == 0, L.ira_last_error(h)
+        rc = L.ira_op_pw_nres(h, ptr(ad), Cp, None, 0, 0, ptr(Wpd), 0, ptr(bpd), ptr(xb), ptr(xb), Cp, Cp // 32, 1, npx)
+        assert rc == 0, L.ira_last_error(h)
+        x1 = xb.clone()
+        rc = L.ira_op_swin_mlp(h, ptr(xb), ptr(W1d), ptr(b1d), ptr(W2d), ptr(b2d), Cp, hid, npx, C.c_float(1e-5), Cr)
+        assert rc == 0, L.ira_last_error(h)
+    finally:
+        if planes == 1:
+            be.close()
+    assert torch.equal(xa, xb)
+    Wq = r16(Wp) if planes == 1 else Wp
+    ref1 = x.clone(); ref1[:, :Cr] += (att.double() @ Wq[:Cr].double().t()).float() + bp[:Cr]
+    close(x1.cpu()[:, :Cr], ref1[:, :Cr], 2e-5, 2e-5)          # the projection step of the two-kernel path itself
+
+
 @pytest.mark.parametrize('Hp,T,H,W,with_bias', [(64, 2, 6, 9, False), (128, 1, 4, 24, False), (32, 1, 2, 3, False),
                                                 (1024, 1, 5, 10, True),      # k_dwconv_gate_row: two chunks of 64 channel octets, rows not a multiple of 4
                                                 (512, 2, 9, 37, True)])       # ragged last 4-pixel step, several row segments per band

@@ -30,5 +30,12 @@ def two():
     rc = L.ira_op_pw_kres_ex(be.handle, p(x), 1, 2, Cp, p(W1), p(b1), p(hbuf), hid, hid, hid // 32, 1, npx, C.c_float(1e-5), 240, 1)
     return rc or L.ira_op_pw_nres(be.handle, p(hbuf), hid, None, 0, 0, p(W2), 0, p(b2), p(x), p(x), Cp, Cp // 32, 1, npx)
 timed(fused, f"fused (dbg {os.environ.get('IRA_SWIN_MLP_DBG', '0')})", npx * Cp * 8)
+att = torch.randn(npx, Cp, device='cuda').half()
+Wp = (torch.randn(2, Cp // 32, Cp // 16, 64, 8, device='cuda') * 0.05).half(); bp = torch.randn(Cp, device='cuda') * 0.1
+pfused = lambda: L.ira_op_swin_proj_mlp(be.handle, p(x), p(att), p(Wp), p(bp), p(W1), p(b1), p(W2), p(b2), Cp, hid, npx, C.c_float(1e-5), 240)
+proj = lambda: L.ira_op_pw_nres(be.handle, p(att), Cp, None, 0, 0, p(Wp), 0, p(bp), p(x), p(x), Cp, Cp // 32, 1, npx)
+if os.environ.get('IRA_SWIN_MLP_DBG', '0') == '0':
+    timed(pfused, "proj + MLP fused", npx * Cp * 14)
+    timed(proj, "proj + residual alone (k_nres_wide)", npx * Cp * 10)
 if os.environ.get('IRA_SWIN_MLP_DBG', '0') == '0':
     timed(two, "two kernels", npx * (Cp * 12 + hid * 4))
