@@ -148,16 +148,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, 
         static_assert(KSI * NPL * NB2 == FS, "a W_p stage fills a stage buffer exactly");
         const char* wplane = (const char*)Wp + lane * 16;
         const long lop = (long)NB2 * KS * 1024;
-        auto pstage = [&](int sti, int buf) {
-#pragma unroll
-            for (int i = 0; i < FS / NW; ++i) {
-                const int f = wave + NW * i;
-                const int ks = f / (NPL * NB2), rem = f - ks * NPL * NB2, plane = rem / NB2, nb = rem - plane * NB2;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wplane + (plane ? lop : 0) + ((long)nb * KS + sti * KSI + ks) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(smem + buf * (WBUF + BBUF) + f * 1024), 16, 0, 0);
-            }
+        auto ppiece = [&](int sti, int i) {                                  // DMA piece i of this wave for W_p stage sti
+            const int f = wave + NW * i;
+            const int ks = f / (NPL * NB2), rem = f - ks * NPL * NB2, plane = rem / NB2, nb = rem - plane * NB2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wplane + (plane ? lop : 0) + ((long)nb * KS + sti * KSI + ks) * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + (sti & 1) * (WBUF + BBUF) + f * 1024), 16, 0, 0);
         };
-        pstage(0, 0);
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) ppiece(0, i);
         const f16* arow = attn + px * K + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) b[s] = *(const half8*)(arow + 16 * s);
@@ -167,20 +165,35 @@ __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc2[nb][8 * u + e] = bp[32 * nb + 16 * u + 8 * h + e];
+        dma_bases();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int sti = 0; sti < PST; ++sti) {
-            if (sti + 1 < PST) pstage(sti + 1, (sti + 1) & 1); else stage(0, 0);
             const half8* cur = (const half8*)(smem + (sti & 1) * (WBUF + BBUF)) + lane;
+            // MFMA order (k-step, row block, plane) as k_nres_wide; fragment (ks, plane, nb) of the stage sits at ks NPL NB2 + plane NB2 + nb
+            auto offp = [](int q) { const int plane = q % NPL, nb = (q / NPL) % NB2, ks = q / (NPL * NB2); return (ks * NPL * NB2 + plane * NB2 + nb) * 64; };
+            constexpr int PFP = 6;                                           // plenty of registers here: no fc1 accumulators yet
+            half8 a[PFP];
 #pragma unroll
-            for (int ks = 0; ks < KSI; ++ks)
+            for (int q = 0; q < PFP; ++q) a[q] = cur[offp(q)];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < NB2; ++nb) {
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(ks * NPL * NB2 + nb) * 64], b[sti * KSI + ks], acc2[nb], 0, 0, 0);
-                    if constexpr (LO) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[(ks * NPL * NB2 + NB2 + nb) * 64], b[sti * KSI + ks], acc2[nb], 0, 0, 0);
+            for (int q = 0; q < FS; ++q) {                                   // the next stage's DMA pieces ride behind every NW-th MFMA, in this order
+                const int nb = (q / NPL) % NB2, ks = q / (NPL * NB2);
+                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % PFP], b[sti * KSI + ks], acc2[nb], 0, 0, 0);
+                if (q + PFP < FS) a[q % PFP] = cur[offp(q + PFP)];
+                if (q % NW == 0) {
+                    const int i = q / NW;
+                    if (sti + 1 < PST) ppiece(sti + 1, i);
+                    else {                                                   // after the last W_p stage: the MLP's stage 0 (fc1 row block 0 and its biases)
+                        if (i == 0) bias_piece_all(0);
+                        if (i < F1 / NW) dma_piece(0, i);
+                    }
                 }
-            if (sti + 1 < PST) {                                              // the last stage's successor (MLP stage 0) is awaited below, with the table
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (sti + 1 < PST) {                                              // the last stage's successor is awaited below, with the table
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
