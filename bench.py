@@ -352,7 +352,10 @@ def main_swinir(args):
         per_px = {'swin_ln_qkv': (2.0 * C * 3 * Kh, 4 * C + 2 * 3 * Kh), 'swin_window_attn': (4.0 * 64 * 32 * 8, 2 * 3 * Kh + 2 * Kh),
                   'swin_proj_res': (2.0 * Kh * C, 2 * Kh + 8 * C), 'swin_ln_fc1_gelu': (2.0 * C * hid, 4 * C + 2 * hid),
                   'swin_fc2_res': (2.0 * hid * C, 2 * hid + 8 * C),
-                  'swin_mlp_fused': (4.0 * C * hid, 8 * C)}.get(key.split('|')[0])       # LN + fc1 + GELU + fc2 + residual: x read and written, nothing else
+                  'swin_mlp_fused': (4.0 * C * hid, 8 * C),                                # LN + fc1 + GELU + fc2 + residual: x read and written, nothing else
+                  # proj + residual + the MLP half-block: attention output (fp16) and x in, x out (the kernel also writes x once and re-reads it
+                  # as the MLP's residual: 8C of implementation traffic that the algorithmic figure does not count)
+                  'swin_proj_mlp_fused': (2.0 * Kh * C + 4.0 * C * hid, 2 * Kh + 8 * C)}.get(key.split('|')[0])
         roof = {'bound': 'hbm', 'kernel': key, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None}
         if per_px:
             avg_ms = prof[key]['ms'] / prof[key]['launches']
