@@ -41,8 +41,10 @@ hipError_t launch_dwconv_gate(hipStream_t st, const void* in, const float* w, co
 hipError_t launch_gram(hipStream_t st, const void* qk, float* part, int T, int nblk, int C, int heads, int S);
 
 // attn_scratch: fp32 [T][heads][c][c]
+// red: room for T x attn_mix_reduce_groups(S) records when that is non-zero (S > 256: frame-wide Grams), or NULL = single-level sum
+int attn_mix_reduce_groups(int S);
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp,
-                           float* attn_scratch, void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero = false);
+                           float* attn_scratch, void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero = false, float* red = nullptr);
 
 // Fused attention front end (ira_qkv_fused.hip): LN + qkv 1x1 + depthwise 3x3 -> q,k (pixel-minor) and v (NHWC).
 bool qkv_fused_supported(int C);

@@ -1804,10 +1804,40 @@ hipError_t launch_sum_records(hipStream_t st, const float* part, int S, int recl
     return hipGetLastError();
 }
 
+// out[t][g][i] = sum over the records s in [g G, min(S, (g + 1) G)) of part[t][s][i], in the fixed order of k_attn_softmax's sum_parts (eight
+// chains).  A frame-wide Gram has up to 2048 partial records per image; k_attn_softmax runs heads x ceil(c / 8) workgroups per image, each
+// adding all of them up with dependent loads - 0.2 ms per block of an untiled 4K frame (9.6 ms of its 194).  Here the first 32-fold of that
+// sum runs on reclen / 256 x S / 32 workgroups.
+__global__ __launch_bounds__(256) void k_reduce_records(const float* __restrict__ part, int S, int G, int reclen, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, t = blockIdx.z, Sp = gridDim.y;
+    if (i >= reclen) return;
+    const int s0 = g * G, n = min(G, S - s0);
+    const float* pb = part + ((long)t * S + s0) * reclen + i;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= n; s += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += pb[(long)(s + u) * reclen];
+    }
+    for (; s < n; ++s) a[0] += pb[(long)s * reclen];
+    out[((long)t * Sp + g) * reclen + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+int attn_mix_reduce_groups(int S) { return S > 256 ? (S + 31) / 32 : 0; }
+
 hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, const float* temp, float* attn_scratch,
-                           void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero) {
+                           void* M, int T, int C, int heads, int S, int NB, bool m_lo_zero, float* red) {
     const int c = C / heads;
     if (c > 96) return hipErrorInvalidValue;
+    const int Sp = attn_mix_reduce_groups(S);
+    if (red != nullptr && Sp > 0) {       // frame-wide Grams only (S depends on the tile geometry alone, never on the batch): two-level sum
+        const int reclen = heads * (c * c + 2 * c);
+        hipLaunchKernelGGL(k_reduce_records, dim3((reclen + 255) / 256, Sp, T), dim3(256), 0, st, part, S, 32, reclen, red);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        part = red;
+        S = Sp;
+    }
     hipLaunchKernelGGL(k_attn_softmax, dim3(T * heads, (c + 7) / 8), dim3(256), 0, st, part, temp, attn_scratch, T, C, heads, S);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

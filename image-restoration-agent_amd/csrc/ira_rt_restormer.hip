@@ -139,7 +139,7 @@ static int ensure_workspace(ira_model* m, int T, int H, int W) {
             mh = std::max(mh, t * g.P[l] * 2 * Hp * 2);
             mg = std::max(mg, t * g.P[l] * Hp * 2);
             mM = std::max(mM, t * 2 * up32(C) * C * 2);
-            mpart = std::max(mpart, t * S * heads * ((size_t)c * c + 2 * c) * 4);
+            mpart = std::max(mpart, t * (S + ira::attn_mix_reduce_groups(S)) * heads * ((size_t)c * c + 2 * c) * 4);   // + the pre-reduced records of a frame-wide Gram
             mattn = std::max(mattn, t * (size_t)C * c * 4);
         }
     }
@@ -318,7 +318,9 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
         if ((rc = strip_gram_mix(m, b, H, W, C, heads, lv, k_[2], k_[3])) != IRA_OK) return rc;
     } else {
         RUN(m, k_[2], ira::launch_gram(st, m->qk, m->part, T, (int)nblk, C, heads, S));
-        RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc, m->w_planes == 1 && hi_plane_level(C)));
+        const int cc = C / heads;
+        float* red = (float*)m->part + (size_t)T * S * heads * ((size_t)cc * cc + 2 * cc);      // behind the S records (ws sizing above)
+        RUN(m, k_[3], ira::launch_attn_mix(st, m->part, b.wo, b.temp, m->attnA, m->M, T, C, heads, S, NBc, m->w_planes == 1 && hi_plane_level(C), red));
     }
     // attention apply x += M_t . v (:127-131 as a per-tile 1x1) and GDFN (:88-93): ONE kernel where the second-generation fused
     // kernel runs (not in band mode: the halo row of x has to be exchanged between the two there)
