@@ -3,7 +3,8 @@ seeded 272 x 272 frame (73984 tokens, above the fused kernel's 32768-token thres
 mean of the fp32 output.  Run once with IRA_SWIN_MLP=0 and once with IRA_SWIN_MLP=1 (the switch is read once per process).  With the
 erf-polynomial GELU in both paths the two runs were bit-identical (commit edbe53c); since the fused kernel takes GELU from the Phi table
 the hashes differ and the means agree to the printed digits (tests/test_gpu_ops.py::test_swin_mlp_fused bounds the difference per element).
-usage (GPU box): IRA_SWIN_MLP=0 python tools/ab_swin_mlp.py; IRA_SWIN_MLP=1 python tools/ab_swin_mlp.py"""
+IRA_SWIN_PROJ_MLP=0/1 (projection as its own launch / folded into the fused kernel) must and does give the SAME hashes.
+usage (GPU box): IRA_SWIN_MLP=0 python tools/ab_swin_mlp.py; IRA_SWIN_MLP=1 python tools/ab_swin_mlp.py; IRA_SWIN_PROJ_MLP=0 python tools/ab_swin_mlp.py"""
 import hashlib, os, sys
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(R, 'image-restoration-agent_amd')); sys.path.insert(0, R)
