@@ -73,7 +73,8 @@ hipError_t launch_nres_wide(hipStream_t st, const void* x, int K, const void* W,
 bool swin_mlp_supported(int Cp, int hidp, long npx);
 hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int Cp, int hidp, long npx,
                            float eps, int ln_n, int planes,
-                           const void* attn = nullptr, const void* Wp = nullptr, const float* bp = nullptr);   // attn != NULL: x += W_p attn + b_p first (attn fp16 (npx, 256))
+                           const void* attn = nullptr, const void* Wp = nullptr, const float* bp = nullptr,    // attn != NULL: x = xin + W_p attn + b_p first (attn fp16 (npx, 256))
+                           const float* xin = nullptr);                                                        // NULL = x (in place); else x is only written: the block's input stays intact
 
 // ira_brighten.hip: tool 0 constant shift, 1 gamma correction, 2 CLAHE (hist_scratch: 64 x 256 u32, lut_scratch: 64 x 256 bytes, tool 2 only)
 hipError_t launch_brighten(hipStream_t st, int tool, const uint8_t* in_rgb, uint8_t* out_rgb, int h, int w, uint32_t* hist_scratch, uint8_t* lut_scratch);

@@ -177,19 +177,24 @@ int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float
         } else {
             for (int q = 0; q < 5; ++q) k_[q][0] = 0;
         }
-        HIP_TRY(m, hipMemcpyAsync(m->sw_xb, m->sw_xa, (size_t)T * P * g.Cp * 4, hipMemcpyDeviceToDevice, st));     // RSTB keeps its input (:482)
+        // The RSTB keeps its input (:482) for the residual behind its convolution.  Where the second half of a block is ONE kernel, the first
+        // block reads that input where it lies (LN + qkv, and the projection's residual) and writes into the working copy: no copy.
+        static const bool proj_fused = [] { const char* v = getenv("IRA_SWIN_PROJ_MLP"); return !(v && *v == '0'); }();
+        const bool mlp1 = ira::swin_mlp_supported(g.Cp, g.hidp, (long)T * P);
+        const bool one_kernel = mlp1 && proj_fused && Kh == g.Cp && c.depths[i] > 0 && m->sw_blocks[i][0].proj_b;
+        if (!one_kernel) HIP_TRY(m, hipMemcpyAsync(m->sw_xb, m->sw_xa, (size_t)T * P * g.Cp * 4, hipMemcpyDeviceToDevice, st));
         float* x = m->sw_xb;
         for (int k = 0; k < c.depths[i]; ++k) {
             const SBlk& b = m->sw_blocks[i][k];
             const int shift = (k % 2 == 0) ? 0 : ws / 2;                                                             // :385-386
-            RUN(m, k_[0], ira::launch_pw_kres(st, x, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0, m->w_planes));
+            const float* xsrc = (one_kernel && k == 0) ? m->sw_xa : x;
+            RUN(m, k_[0], ira::launch_pw_kres(st, xsrc, true, 2, g.Cp, b.qkv_w, b.qkv_b, m->sw_qkv, 3 * Kh, 3 * Kh, 3 * heads, T, P, 1e-5f, g.C, 0, m->w_planes));
             RUN(m, k_[1], ira::launch_swin_attn(st, m->sw_qkv, b.bias_tab, m->sw_att, T, Hp, Wp, heads, ws, shift));
-            static const bool proj_fused = [] { const char* v = getenv("IRA_SWIN_PROJ_MLP"); return !(v && *v == '0'); }();
-            const bool mlp1 = ira::swin_mlp_supported(g.Cp, g.hidp, (long)T * P);
             if (mlp1 && proj_fused && Kh == g.Cp && b.proj_b) {            // proj + residual + LN + fc1 + GELU + fc2 + residual: the second half of the block in one kernel
                 char km[64];
                 if (m->profile) snprintf(km, sizeof km, "swin_proj_mlp_fused|C%d|%dx%d|T%d", g.C, Hp, Wp, T); else km[0] = 0;
-                RUN(m, km, ira::launch_swin_mlp(st, x, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, g.Cp, g.hidp, (long)T * P, 1e-5f, g.C, m->w_planes, m->sw_att, b.proj_w, b.proj_b));
+                RUN(m, km, ira::launch_swin_mlp(st, x, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b, g.Cp, g.hidp, (long)T * P, 1e-5f, g.C, m->w_planes, m->sw_att, b.proj_w, b.proj_b,
+                                                xsrc == x ? nullptr : xsrc));
                 continue;
             }
             RUN(m, k_[2], ira::launch_pw_nres(st, m->sw_att, Kh, nullptr, 0, false, b.proj_w, 0, b.proj_b, x, x, g.Cp, g.Cp / 32, T, P, m->w_planes));

@@ -50,7 +50,7 @@ template <bool LO, int NW, bool PROJ, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, const f16* __restrict__ W1, const float* __restrict__ b1,
                                                          const f16* __restrict__ W2, const float* __restrict__ b2, const float2* __restrict__ phi,
                                                          const f16* __restrict__ attn, const f16* __restrict__ Wp, const float* __restrict__ bp,
-                                                         int NB1, long npx, float eps, int ln_n) {
+                                                         const float* xin, int NB1, long npx, float eps, int ln_n) {
     constexpr int KS = MLP_KS, NB2 = MLP_NB2, K = KS * 16;
     constexpr int NPL = LO ? 2 : 1;
     constexpr int F1 = NPL * KS, F2 = NPL * 2 * NB2, FS = F1 + F2;          // 1 KB fragments per stage: fc1 [plane][k-step], fc2 [k-step][plane][row block]
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_swin_mlp(float* __restrict__ x, 
             }
         }
         // residual in accumulator layout, the sums of the LayerNorm in the order of the load-based prologue, x1 back to memory
-        const float* xr = x + px * K + 8 * h;
+        const float* xr = xin + px * K + 8 * h;                             // xin == x, or the block's input kept elsewhere (x then only receives)
         float* xw = x + (p0 + r) * K + 8 * h;
         float sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -451,7 +451,7 @@ bool swin_mlp_supported(int Cp, int hidp, long npx) {
 
 struct MlpArgs {
     float* x; const void* W1; const float* b1; const void* W2; const float* b2;
-    const void* attn; const void* Wp; const float* bp;                      // attention projection in front (PROJ), or all NULL
+    const void* attn; const void* Wp; const float* bp; const float* xin;    // attention projection in front (PROJ), or all NULL; xin: where PROJ reads x
     int NB1; long npx; float eps; int ln_n;
 };
 
@@ -466,16 +466,17 @@ static hipError_t swin_mlp_launch(hipStream_t st, const MlpArgs& a) {
     static std::atomic<uint64_t> done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)k_swin_mlp<LO, NW, PROJ, DBG>, smem, done); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_swin_mlp<LO, NW, PROJ, DBG>), grid, block, smem, st, a.x, (const f16*)a.W1, a.b1, (const f16*)a.W2, a.b2, phi, (const f16*)a.attn,
-                       (const f16*)a.Wp, a.bp, a.NB1, a.npx, a.eps, a.ln_n);
+                       (const f16*)a.Wp, a.bp, a.xin, a.NB1, a.npx, a.eps, a.ln_n);
     return hipGetLastError();
 }
 
 hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float* b1, const void* W2, const float* b2, int Cp, int hidp, long npx,
-                           float eps, int ln_n, int planes, const void* attn, const void* Wp, const float* bp) {
+                           float eps, int ln_n, int planes, const void* attn, const void* Wp, const float* bp, const float* xin) {
     if (!swin_mlp_supported(Cp, hidp, npx) || !b1 || !b2) return hipErrorInvalidValue;
     const bool proj = attn != nullptr;
     if (proj && (!Wp || !bp)) return hipErrorInvalidValue;
-    const MlpArgs a{x, W1, b1, W2, b2, attn, Wp, bp, hidp / 32, npx, eps, ln_n};
+    if (xin != nullptr && !proj) return hipErrorInvalidValue;              // only the projection step reads x before anything is written
+    const MlpArgs a{x, W1, b1, W2, b2, attn, Wp, bp, xin ? xin : x, hidp / 32, npx, eps, ln_n};
     // plain fp16 weights: 64.5 KB of LDS per workgroup of FOUR waves, two workgroups per CU (their load / MFMA / store phases overlap);
     // hi + lo planes: 128.5 KB, one workgroup of eight waves
     if (planes == 1) {
