@@ -12,6 +12,10 @@ const char* last_error();                       // of the calling thread
 bool get_unique_id(void* id128);                // ncclGetUniqueId
 Comm* init_rank(const void* id128, int rank, int world);       // ncclCommInitRank on the CURRENT device
 void destroy(Comm* c);
+void abort(Comm* c);                            // ncclCommAbort: local collectives in flight end with an error; the Comm stays allocated but unusable
+bool usable(const Comm* c);                     // false after abort()
+// wait for `st` (collectives included) with a deadline; on time-out or an asynchronous RCCL error: abort(c), false, last_error() says why
+bool sync(Comm* c, hipStream_t st, long timeout_ms);
 int rank(const Comm* c);
 int world(const Comm* c);
 // every call enqueues on `st` and returns at once (no host synchronisation)

@@ -5,10 +5,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 namespace ira_comm {
 
@@ -27,6 +30,8 @@ struct Api {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                 // optional: a library without it only loses the abort path
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr; // optional
     std::string why;
 };
 
@@ -34,12 +39,21 @@ Api* api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
+        // IRA_RCCL_LIB names the one library to try (a site build of RCCL; also how the tests provoke the failure path)
+        const char* forced = getenv("IRA_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
+        std::string first_err;
+        auto try_open = [&](const char* n) {
+            dlerror();
             a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (a.lib) break;
-        }
-        if (!a.lib) { a.why = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+            if (!a.lib && first_err.empty()) {
+                const char* e = dlerror();          // ONE call: a second dlerror() returns NULL and invalidates the first string
+                first_err = e ? e : "?";
+            }
+        };
+        if (forced && *forced) try_open(forced);
+        else for (const char* n : names) { try_open(n); if (a.lib) break; }
+        if (!a.lib) { a.why = std::string("cannot load librccl.so: ") + first_err; return; }
 #define IRA_SYM(field, name)                                                                          \
     a.field = (decltype(a.field))dlsym(a.lib, name);                                                   \
     if (!a.field) { a.why = std::string("librccl.so lacks ") + name; return; }
@@ -47,6 +61,8 @@ Api* api() {
         IRA_SYM(AllGather, "ncclAllGather") IRA_SYM(Send, "ncclSend") IRA_SYM(Recv, "ncclRecv") IRA_SYM(GroupStart, "ncclGroupStart")
         IRA_SYM(GroupEnd, "ncclGroupEnd") IRA_SYM(GetErrorString, "ncclGetErrorString")
 #undef IRA_SYM
+        a.CommAbort = (decltype(a.CommAbort))dlsym(a.lib, "ncclCommAbort");
+        a.CommGetAsyncError = (decltype(a.CommGetAsyncError))dlsym(a.lib, "ncclCommGetAsyncError");
     });
     if (!a.why.empty()) { t_err = a.why; return nullptr; }
     return &a;
@@ -95,12 +111,57 @@ void destroy(Comm* c) {
     delete c;
 }
 
+void abort(Comm* c) {
+    if (!c || !c->comm) return;
+    Api* a = api();
+    if (a && a->CommAbort) a->CommAbort(c->comm);           // frees the communicator: its kernels see the abort flag and leave
+    else if (a) a->CommDestroy(c->comm);
+    c->comm = nullptr;
+}
+
+bool usable(const Comm* c) { return c && c->comm; }
+
+// Host-side wait for everything enqueued on `st`, the collectives included.  A peer that never enters a collective (it failed an
+// argument check, ran out of memory, died) would otherwise leave this rank's RCCL kernel spinning for ever and hipStreamSynchronize
+// with it: poll the stream and the communicator's asynchronous error state instead, and after `timeout_ms` (or on an asynchronous
+// error) abort the communicator, which makes the local kernel exit, and report.  The communicator is unusable afterwards.
+bool sync(Comm* c, hipStream_t st, long timeout_ms) {
+    Api* a = api();
+    if (!a || !usable(c)) { if (a) t_err = "communicator was aborted"; return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) { t_err = std::string("stream: ") + hipGetErrorString(q); abort(c); return false; }
+        if (a->CommGetAsyncError) {
+            ncclResult_t ar = ncclSuccess;
+            if (a->CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                t_err = std::string("asynchronous RCCL error: ") + a->GetErrorString(ar);
+                abort(c);
+                (void)hipStreamSynchronize(st);
+                return false;
+            }
+        }
+        const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_ms > 0 && ms > timeout_ms) {
+            t_err = "collective did not complete within " + std::to_string(timeout_ms) + " ms (a peer rank failed or never entered it); communicator aborted";
+            abort(c);
+            (void)hipStreamSynchronize(st);
+            return false;
+        }
+        if (++spins < 2000) std::this_thread::yield();     // the first ~ms: a frame normally completes here
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 int rank(const Comm* c) { return c->rank; }
 int world(const Comm* c) { return c->world; }
 
 bool all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank, hipStream_t st) {
     Api* a = api();
     if (!a) return false;
+    if (!usable(c)) { t_err = "communicator was aborted"; return false; }
     return ok(a, a->AllGather(send, recv, bytes_per_rank, ncclUint8, c->comm, st), "ncclAllGather");
 }
 
@@ -109,6 +170,7 @@ bool exchange_neighbours(Comm* c, int up, const void* send_up, void* recv_up, in
     Api* a = api();
     if (!a) return false;
     if (up < 0 && down < 0) return true;
+    if (!usable(c)) { t_err = "communicator was aborted"; return false; }
     if (!ok(a, a->GroupStart(), "ncclGroupStart")) return false;
     bool good = true;
     if (up >= 0) {

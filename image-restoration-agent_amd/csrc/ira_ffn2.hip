@@ -132,7 +132,11 @@ IRA_DEV float gelu_gate_tab(float a, float b, const float2* tab) {
 // DBG (diagnostic builds of ONE instantiation, selected with IRA_FFN2_DBG at launch; results are wrong or slower, never shipped on a
 // product path): 1 = unit weights are constants (no scalar loads), 2 = no vector work at all, 3 = no project_in MFMAs, 4 = s_memtime stamps,
 // 12 = 2 + no hidden write-out, 13 = 12 + no project_out MFMAs, 14 = 13 + no project_in MFMAs (barriers, weight loads and LDS fragment reads only)
+// They exist only in a -DIRA_KERNEL_DBG build (tools/time_ffn2.py, tools/pmc_ffn2.sh: `make dbg` -> libira_hip_dbg.so); the product library
+// instantiates DBG = 0 alone and reads no IRA_FFN2_DBG, so an inherited environment cannot change its results.
+#ifdef IRA_KERNEL_DBG
 __device__ unsigned long long g_ffn2_stamps[2][64];
+#endif
 
 template <int C, int LN, bool BIN, bool CB, bool FOLD, int DBG = 0>
 __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float* __restrict__ xo, const f16* __restrict__ v,
@@ -164,14 +168,18 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     const int NBH = Hp >> 5;              // 32-row blocks of x1 in W_in (x2's blocks follow)
     const bool isC = wave >= 4;
     const int cw = wave - 4;
-    int stamp_n = 0;
+    [[maybe_unused]] int stamp_n = 0;
     auto STAMP = [&]() {
+#ifdef IRA_KERNEL_DBG
         if ((DBG == 4 || DBG == 9) && blockIdx.x == 777 && lane == 0 && (wave == 0 || wave == 4) && stamp_n < (DBG == 9 ? 32 : 64)) g_ffn2_stamps[wave >> 2][stamp_n] = __builtin_amdgcn_s_memtime();
         ++stamp_n;
+#endif
     };
-    int sstamp_n = 32;
+    [[maybe_unused]] int sstamp_n = 32;
     auto SLOTSTAMP = [&](int i) {
+#ifdef IRA_KERNEL_DBG
         if (DBG == 9 && i == 5 && blockIdx.x == 777 && lane == 0 && (wave == 0 || wave == 4) && sstamp_n < 64) g_ffn2_stamps[wave >> 2][sstamp_n++] = __builtin_amdgcn_s_memtime();
+#endif
     };
     STAMP();
     // Phase stagger.  Every workgroup takes the same time, so without this all 256 CUs run their prologues (130 KB of x each = 33 MB
@@ -668,9 +676,11 @@ hipError_t phi_table(const float2** out) {
     return hipSuccess;
 }
 
+#ifdef IRA_KERNEL_DBG
 extern "C" int ira_debug_ffn2_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffn2_stamps), sizeof(unsigned long long) * 128);
 }
+#endif
 
 bool ffn2_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0; }
 
@@ -687,6 +697,7 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     static const int stagger_env = getenv("IRA_FFN2_STAGGER") ? atoi(getenv("IRA_FFN2_STAGGER")) : 3;   // s_sleep(127) units per phase step
     const int stagger = nblk >= 1024 ? stagger_env : 0;          // only where a CU runs several patches
+#ifdef IRA_KERNEL_DBG
     if constexpr (C == 96 && LN == 1 && !BIN && !CB && !FOLD) {
         static const int dbg = getenv("IRA_FFN2_DBG") ? atoi(getenv("IRA_FFN2_DBG")) : 0;
 #define IRA_DBG_LAUNCH(D_)                                                                                                                     \
@@ -700,6 +711,7 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
         IRA_DBG_LAUNCH(1) IRA_DBG_LAUNCH(2) IRA_DBG_LAUNCH(3) IRA_DBG_LAUNCH(4) IRA_DBG_LAUNCH(5) IRA_DBG_LAUNCH(6) IRA_DBG_LAUNCH(7) IRA_DBG_LAUNCH(8) IRA_DBG_LAUNCH(9) IRA_DBG_LAUNCH(12) IRA_DBG_LAUNCH(13) IRA_DBG_LAUNCH(14) IRA_DBG_LAUNCH(15) IRA_DBG_LAUNCH(16)
 #undef IRA_DBG_LAUNCH
     }
+#endif
     hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
                        Wout, bout, tab, T, H, W, Hp, stagger);
     return hipGetLastError();

@@ -120,6 +120,7 @@ struct ira_model {
     float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
     bool use_fused_ffn = true;
     int ffn_gen = 2;
+    char* lo_backup = nullptr;           // device copy of the lo planes that w_planes == 1 zeroed (ira_set_weight_planes(2) puts them back)
     int w_planes = 2;          // ira_set_weight_planes: 1 = the 1x1 layers of this model use the hi plane alone where a kernel for that exists                  // 2: ira_ffn2.hip (attention apply folded in); 1: ira_ffn_fused.hip + separate apply (IRA_FFN_GEN=1)
     // strip-parallel whole-frame forward (ira_strip_*): this rank's band of rows with halo rows of its neighbours
     bool strip_set = false, strip_on = false;
@@ -227,8 +228,8 @@ int naf_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, floa
 bool dn_bind_weights(ira_model* m);
 int dn_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool sw_bind_weights(ira_model* m);
-int sw_zero_lo_planes(ira_model* m);          // ira_set_weight_planes(1) on a SwinIR handle
-int restormer_zero_lo_planes(ira_model* m);   // ... on a Restormer / X-Restormer handle (levels with C = 192 / 384 only)
+void sw_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& out);          // the lo-plane regions ira_set_weight_planes(1) zeroes on a SwinIR handle
+void restormer_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& out);   // the same for Restormer / X-Restormer (levels with C = 192 / 384)
 int sw_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);
 bool rr_bind_weights(ira_model* m);
 int rr_forward_enqueue(ira_model* m, const float* in, int T, int H, int W, float* out);

@@ -167,11 +167,9 @@ static int ensure_workspace(ira_model* m, int T, int H, int W) {
 // through two-plane kernels compute the same numbers (x * 0 adds nothing): a tile's result stays independent of its launch batch.
 static bool hi_plane_level(int C) { return C == 192 || C == 384; }
 
-int restormer_zero_lo_planes(ira_model* m) {
+void restormer_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& out) {
     const ira_restormer_config& c = m->cfg;
-    auto zero = [&](const void* w, size_t total) -> hipError_t {
-        return w ? hipMemsetAsync((char*)const_cast<void*>(w) + total / 2, 0, total / 2, m->st) : hipSuccess;
-    };
+    auto add = [&](const void* w, size_t total) { if (w) out.emplace_back((char*)const_cast<void*>(w) + total / 2, total / 2); };
     std::vector<Blk>* stages[8] = {&m->enc1, &m->enc2, &m->enc3, &m->lat, &m->dec3, &m->dec2, &m->dec1, &m->refine};
     const int lvl[8] = {0, 1, 2, 3, 2, 1, 0, 0};
     for (int si = 0; si < 8; ++si) {
@@ -180,18 +178,16 @@ int restormer_zero_lo_planes(ira_model* m) {
         if (!hi_plane_level(C)) continue;
         const size_t Hp = up32((si >= 6) ? c.hidden[1] : c.hidden[l]), NBq = up32(3 * C), NBc = up32(C);
         for (Blk& b : *stages[si]) {
-            HIP_TRY(m, zero(b.qkv_w, 2 * NBq * C * 2));
-            HIP_TRY(m, zero(b.pin_w, (size_t)2 * 2 * Hp * C * 2));
-            HIP_TRY(m, zero(b.pout_w, 2 * NBc * Hp * 2));
+            add(b.qkv_w, 2 * NBq * C * 2);
+            add(b.pin_w, (size_t)2 * 2 * Hp * C * 2);
+            add(b.pout_w, 2 * NBc * Hp * 2);
             if (m->xr) {
                 // (the OCAB 1x1s keep both planes: their K = 16 * heads has no hi-plane kernel)
-                HIP_TRY(m, zero(b.pin2_w, (size_t)2 * 2 * Hp * C * 2));
-                HIP_TRY(m, zero(b.pout2_w, 2 * NBc * Hp * 2));
+                add(b.pin2_w, (size_t)2 * 2 * Hp * C * 2);
+                add(b.pout2_w, 2 * NBc * Hp * 2);
             }
         }
     }
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    return IRA_OK;
 }
 
 // GDFN + residual (restormer_arch.py:88-93,149): fused kernel where supported (writes x -> alt, the two are swapped), else three kernels.

@@ -31,23 +31,19 @@ static bool sw_load_conv(ira_model* m, const std::string& p, bool three, const S
 
 // ira_set_weight_planes(1) on a SwinIR handle: the lo planes of the transformer 1x1 weights are zeroed in the handle's copy of the blob (see
 // restormer_zero_lo_planes), whatever the embedding size; the frame-sized launches of K = 192 / 256 layers then skip the zero plane.
-int sw_zero_lo_planes(ira_model* m) {
+void sw_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& out) {
     const ira_swinir_config& c = m->scfg;
     const SwGeo g = sw_geo(c);
-    auto zero = [&](const void* w, size_t total) -> hipError_t {
-        return w ? hipMemsetAsync((char*)const_cast<void*>(w) + total / 2, 0, total / 2, m->st) : hipSuccess;
-    };
+    auto add = [&](const void* w, size_t total) { if (w) out.emplace_back((char*)const_cast<void*>(w) + total / 2, total / 2); };
     for (int i = 0; i < c.n_layers; ++i) {
         const size_t Kh = (size_t)c.num_heads[i] * 32;
         for (SBlk& b : m->sw_blocks[i]) {
-            HIP_TRY(m, zero(b.qkv_w, (size_t)2 * 3 * Kh * g.Cp * 2));
-            HIP_TRY(m, zero(b.proj_w, (size_t)2 * g.Cp * Kh * 2));
-            HIP_TRY(m, zero(b.fc1_w, (size_t)2 * g.hidp * g.Cp * 2));
-            HIP_TRY(m, zero(b.fc2_w, (size_t)2 * g.Cp * g.hidp * 2));
+            add(b.qkv_w, (size_t)2 * 3 * Kh * g.Cp * 2);
+            add(b.proj_w, (size_t)2 * g.Cp * Kh * 2);
+            add(b.fc1_w, (size_t)2 * g.hidp * g.Cp * 2);
+            add(b.fc2_w, (size_t)2 * g.Cp * g.hidp * 2);
         }
     }
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    return IRA_OK;
 }
 
 bool sw_bind_weights(ira_model* m) {

@@ -193,6 +193,15 @@ int ira_device_count(int* count) {
     return IRA_OK;
 }
 
+static int set_weight_planes_locked(ira_model_t* m, int planes);
+// Product default of the handles that have hi-plane kernels (Restormer, X-Restormer, SwinIR): plain fp16 weights in those layers
+// (ira_set_weight_planes(1)).  Applied by the create function itself so that a C caller and the Python backends start from the
+// same numerics; ira_set_weight_planes(m, 2) restores hi + lo everywhere.
+static int apply_default_planes(ira_model* m) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    return set_weight_planes_locked(m, 1);
+}
+
 int ira_model_create(int device, const ira_restormer_config* cfg, const void* blob, size_t bytes, ira_model_t** out) {
     if (!cfg || !blob || !out) return gfail(IRA_ERR_ARG, "ira_model_create: NULL argument");
     *out = nullptr;
@@ -222,6 +231,7 @@ int ira_model_create(int device, const ira_restormer_config* cfg, const void* bl
         ira_model_destroy(m);
         return IRA_ERR_WEIGHTS;
     }
+    if (int prc = apply_default_planes(m); prc != IRA_OK) { g_err = m->err; ira_model_destroy(m); return prc; }
     *out = m;
     return IRA_OK;
 }
@@ -259,6 +269,7 @@ int ira_xrestormer_create(int device, const ira_xrestormer_config* cfg, const vo
         ira_model_destroy(m);
         return IRA_ERR_WEIGHTS;
     }
+    if (int prc = apply_default_planes(m); prc != IRA_OK) { g_err = m->err; ira_model_destroy(m); return prc; }
     *out = m;
     return IRA_OK;
 }
@@ -380,6 +391,7 @@ int ira_swinir_create(int device, const ira_swinir_config* cfg, const void* blob
         ira_model_destroy(m);
         return IRA_ERR_WEIGHTS;
     }
+    if (int prc = apply_default_planes(m); prc != IRA_OK) { g_err = m->err; ira_model_destroy(m); return prc; }
     *out = m;
     return IRA_OK;
 }
@@ -389,6 +401,7 @@ int ira_model_destroy(ira_model_t* m) {
     hipSetDevice(m->device);
     if (m->st) hipStreamSynchronize(m->st);
     if (m->comm) ira_comm::destroy(m->comm);
+    if (m->lo_backup) hipFree(m->lo_backup);
     if (m->strip_buf) hipFree(m->strip_buf);
     if (m->strip_desc) hipFree(m->strip_desc);
     if (m->dist_tiles) hipFree(m->dist_tiles);
@@ -463,6 +476,25 @@ int ira_strip_buffer_bytes(ira_model_t* m, int Wp, uint64_t* edge_bytes, uint64_
 }
 
 // ---- RCCL behind the ABI (ira_comm.hip)
+// End of a distributed call: wait for the model's stream with a deadline (IRA_COMM_TIMEOUT_MS, default 120 s, 0 = no deadline).  A peer that
+// left before the collective (bad argument, out of memory, crash) would otherwise leave this rank blocked for ever: on time-out or an
+// asynchronous RCCL error the communicator is aborted (ncclCommAbort: the local kernel exits), the call returns IRA_ERR_COMM and every
+// later distributed call on this handle fails at once until ira_comm_init installs a new communicator.
+static int comm_sync(ira_model_t* m, const char* what) {
+    static const long timeout_ms = getenv("IRA_COMM_TIMEOUT_MS") ? atol(getenv("IRA_COMM_TIMEOUT_MS")) : 120000;
+    if (ira_comm::world(m->comm) <= 1) { HIP_TRY(m, hipStreamSynchronize(m->st)); return IRA_OK; }
+    if (!ira_comm::sync(m->comm, m->st, timeout_ms)) return m->fail(IRA_ERR_COMM, "%s: %s", what, ira_comm::last_error());
+    return IRA_OK;
+}
+// A rank that fails locally after its peers may already be inside the collective aborts its communicator, so that (a) nothing of this
+// rank stays enqueued behind a collective that will never complete and (b) the peers' deadline / asynchronous error check ends them.
+static int comm_fail(ira_model_t* m, int rc) {
+    if (rc != IRA_OK && m->comm && ira_comm::usable(m->comm) && ira_comm::world(m->comm) > 1) {
+        ira_comm::abort(m->comm);
+        m->strip_rccl = false;
+    }
+    return rc;
+}
 int ira_comm_unique_id(void* id_out) {
     if (!id_out) return gfail(IRA_ERR_ARG, "ira_comm_unique_id: NULL buffer");
     if (!ira_comm::get_unique_id(id_out)) return gfail(IRA_ERR_COMM, "%s", ira_comm::last_error());
@@ -538,11 +570,10 @@ static void strip_rows(int Hp, int world, int rank, int* r0, int* r1, int* rows_
     *rows_max = 8 * (base + (rem ? 1 : 0));
 }
 
-int ira_strip_restore_u8_device(ira_model_t* m, const uint8_t* frame, int h, int w, int c, uint8_t* out) {
-    ENTER(m);
+static int strip_restore_u8_device_impl(ira_model_t* m, const uint8_t* frame, int h, int w, int c, uint8_t* out) {
     if (!frame || !out) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: NULL buffer");
     if (m->arch != 0 || m->xr) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: Restormer handles only");
-    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: no communicator (ira_comm_init)");
+    if (!m->comm || !ira_comm::usable(m->comm)) return m->fail(IRA_ERR_ARG, "ira_strip_restore_u8_device: no usable communicator (ira_comm_init)");
     if (c != m->cfg.inp_channels || h <= 0 || w <= 0) return m->fail(IRA_ERR_ARG, "image is %dx%dx%d, model wants %d channels", h, w, c, m->cfg.inp_channels);
     const int Hp = (h % 8) ? ((h + 8) / 8) * 8 : h, Wp = (w % 8) ? ((w + 8) / 8) * 8 : w;      // demo.py:123-126: pad only where needed
     const int rank = ira_comm::rank(m->comm), world = ira_comm::world(m->comm);
@@ -582,8 +613,12 @@ int ira_strip_restore_u8_device(ira_model_t* m, const uint8_t* frame, int h, int
             if (rows > 0) HIP_TRY(m, hipMemcpyAsync(out + (size_t)a * w * c, gbuf + slot * i, (size_t)rows * w * c, hipMemcpyDeviceToDevice, m->st));
         }
     }
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    return IRA_OK;
+    return comm_sync(m, "ira_strip_restore_u8_device");
+}
+
+int ira_strip_restore_u8_device(ira_model_t* m, const uint8_t* frame, int h, int w, int c, uint8_t* out) {
+    ENTER(m);
+    return comm_fail(m, strip_restore_u8_device_impl(m, frame, h, w, c, out));
 }
 
 int ira_strip_forward_device(ira_model_t* m, const float* in, int H, int W, int halo_top, int halo_bot, float* out) {
@@ -658,10 +693,9 @@ int ira_restore_tiles_device(ira_model_t* m, const uint8_t* frame, int h, int w,
     return IRA_OK;
 }
 
-int ira_restore_frame_distributed(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap, uint8_t* out) {
-    ENTER(m);
+static int restore_frame_distributed_impl(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap, uint8_t* out) {
     if (!frame || !out) return m->fail(IRA_ERR_ARG, "ira_restore_frame_distributed: NULL buffer");
-    if (!m->comm) return m->fail(IRA_ERR_ARG, "ira_restore_frame_distributed: no communicator (ira_comm_init)");
+    if (!m->comm || !ira_comm::usable(m->comm)) return m->fail(IRA_ERR_ARG, "ira_restore_frame_distributed: no usable communicator (ira_comm_init)");
     if (c != m->cfg.inp_channels) return m->fail(IRA_ERR_ARG, "image has %d channels, model wants %d", c, m->cfg.inp_channels);
     Plan p; std::string err;
     int rc = plan_for(m, h, w, tile, overlap, p, err);
@@ -684,8 +718,12 @@ int ira_restore_frame_distributed(ira_model_t* m, const uint8_t* frame, int h, i
     if (world > 1 && !ira_comm::all_gather(m->comm, mine, m->dist_tiles, tile_bytes * chunk, m->st))       // in place, on the model's stream
         return m->fail(IRA_ERR_COMM, "tile all-gather: %s", ira_comm::last_error());
     if ((rc = blend_enqueue(m, m->dist_tiles, h, w, c, p, out)) != IRA_OK) return rc;
-    HIP_TRY(m, hipStreamSynchronize(m->st));
-    return IRA_OK;
+    return comm_sync(m, "ira_restore_frame_distributed");
+}
+
+int ira_restore_frame_distributed(ira_model_t* m, const uint8_t* frame, int h, int w, int c, int tile, int overlap, uint8_t* out) {
+    ENTER(m);
+    return comm_fail(m, restore_frame_distributed_impl(m, frame, h, w, c, tile, overlap, out));
 }
 
 int ira_blend_tiles_device(ira_model_t* m, const float* tiles, int h, int w, int c, int tile, int overlap, uint8_t* out) {
@@ -947,17 +985,45 @@ int ira_op_ffn2(ira_model_t* m, const float* x, float* xo, const void* v, const 
     OP_BODY(m, "op", ira::launch_ffn2(m->st, x, xo, v, M, m_tile_stride, wo_b, ln_mode, C, Win, bin, dwu, dwub, Wout, bout, T, H, W, Hp));
 }
 
+// planes 1: the lo planes of the layers that have a hi-plane kernel are saved to a device-side copy and zeroed in the handle's blob, so that
+// launches too small for the hi-plane kernels (which then run the two-plane ones) still give the same numbers; planes 2 copies them back.
+static int set_weight_planes_locked(ira_model_t* m, int planes) {
+    if (planes == m->w_planes) return IRA_OK;
+    std::vector<std::pair<void*, size_t>> reg;
+    if (m->arch == 0) restormer_lo_planes(m, reg);               // Restormer / X-Restormer: levels with C = 192 / 384
+    else if (m->arch == 3) sw_lo_planes(m, reg);                 // SwinIR: the transformer 1x1s
+    else return IRA_OK;                                          // other architectures have no hi-plane kernels: the setting is ignored
+    size_t total = 0;
+    for (auto& r : reg) total += al256(r.second);
+    if (planes == 1) {
+        if (!m->lo_backup && total) {
+            hipError_t he = hipMalloc((void**)&m->lo_backup, total);
+            if (he != hipSuccess) { m->lo_backup = nullptr; return m->fail(IRA_ERR_OOM, "lo-plane backup hipMalloc(%zu): %s", total, hipGetErrorString(he)); }
+            size_t off = 0;
+            for (auto& r : reg) { HIP_TRY(m, hipMemcpyAsync(m->lo_backup + off, r.first, r.second, hipMemcpyDeviceToDevice, m->st)); off += al256(r.second); }
+        }
+        for (auto& r : reg) HIP_TRY(m, hipMemsetAsync(r.first, 0, r.second, m->st));
+    } else {
+        size_t off = 0;
+        if (m->lo_backup)
+            for (auto& r : reg) { HIP_TRY(m, hipMemcpyAsync(r.first, m->lo_backup + off, r.second, hipMemcpyDeviceToDevice, m->st)); off += al256(r.second); }
+    }
+    HIP_TRY(m, hipStreamSynchronize(m->st));
+    m->w_planes = planes;
+    return IRA_OK;
+}
+
 int ira_set_weight_planes(ira_model_t* m, int planes) {
     ENTER(m);
     if (planes != 1 && planes != 2) return m->fail(IRA_ERR_ARG, "ira_set_weight_planes: 1 (hi plane only) or 2 (hi + lo)");
-    if (planes == m->w_planes) return IRA_OK;
-    if (planes == 2) return m->fail(IRA_ERR_ARG, "ira_set_weight_planes: the lo planes of this handle were zeroed by an earlier call with 1; create a new handle for hi + lo weights");
-    int rc = IRA_OK;
-    if (m->arch == 0) rc = restormer_zero_lo_planes(m);          // Restormer / X-Restormer: levels with C = 192 / 384
-    else if (m->arch == 3) rc = sw_zero_lo_planes(m);
-    else return IRA_OK;                                          // other architectures have no hi-plane kernels: the setting is ignored
-    if (rc != IRA_OK) return rc;
-    m->w_planes = 1;
+    return set_weight_planes_locked(m, planes);
+}
+
+int ira_get_weight_planes(ira_model_t* m, int* planes) {
+    if (!m) return gfail(IRA_ERR_ARG, "ira_get_weight_planes: model is NULL");
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!planes) return m->fail(IRA_ERR_ARG, "ira_get_weight_planes: NULL argument");
+    *planes = m->w_planes;
     return IRA_OK;
 }
 

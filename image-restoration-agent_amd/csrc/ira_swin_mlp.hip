@@ -480,6 +480,7 @@ hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float
     // plain fp16 weights: 64.5 KB of LDS per workgroup of FOUR waves, two workgroups per CU (their load / MFMA / store phases overlap);
     // hi + lo planes: 128.5 KB, one workgroup of eight waves
     if (planes == 1) {
+#ifdef IRA_KERNEL_DBG                      // measurement variants (wrong results): only in the `make dbg` library, never in the product one
         static const int dbg = env_int_m("IRA_SWIN_MLP_DBG", 0);
         if (!proj) switch (dbg) {
             case 1: return swin_mlp_launch<false, 4, false, 1>(st, a);
@@ -487,9 +488,10 @@ hipError_t launch_swin_mlp(hipStream_t st, float* x, const void* W1, const float
             case 3: return swin_mlp_launch<false, 4, false, 3>(st, a);
             case 4: return swin_mlp_launch<false, 4, false, 4>(st, a);
             case 5: return swin_mlp_launch<false, 4, false, 5>(st, a);
-            default: return swin_mlp_launch<false, 4, false, 0>(st, a);
+            default: break;
         }
-        return swin_mlp_launch<false, 4, true, 0>(st, a);
+#endif
+        return proj ? swin_mlp_launch<false, 4, true, 0>(st, a) : swin_mlp_launch<false, 4, false, 0>(st, a);
     }
     return proj ? swin_mlp_launch<true, 8, true, 0>(st, a) : swin_mlp_launch<true, 8, false, 0>(st, a);
 }

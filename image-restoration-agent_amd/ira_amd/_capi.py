@@ -128,6 +128,7 @@ SIGNATURES = {
     'ira_op_ffn2': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     'ira_set_ffn_generation': (_i, [_vp, _i]),
     'ira_set_weight_planes': (_i, [_vp, _i]),
+    'ira_get_weight_planes': (_i, [_vp, _vp]),
     'ira_op_qkv_fused': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'ira_set_fused_ffn': (_i, [_vp, _i]),
     'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),

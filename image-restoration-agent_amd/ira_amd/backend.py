@@ -192,9 +192,16 @@ class _Backend:
         self._ck(self._lib.ira_strip_restore_u8_device(self._h, frame.data_ptr(), h, w, c, out.data_ptr()), 'ira_strip_restore_u8_device')
 
     def set_weight_planes(self, planes: int):
-        """ira_set_weight_planes: 2 = hi + lo fp16 weight planes everywhere (default), 1 = hi plane alone in the 1x1 layers that have a
-        kernel for it (SwinIR handles; measured: tools/ablate_lo_swinir.py)."""
+        """ira_set_weight_planes: 1 = hi plane alone in the 1x1 layers that have a kernel for it (the state of a Restormer / X-Restormer /
+        SwinIR handle after create, for C and Python callers alike), 2 = hi + lo fp16 weight planes everywhere.  Either way round on the
+        same handle: the lo planes are kept in a device-side copy."""
         self._ck(self._lib.ira_set_weight_planes(self._h, int(planes)), 'ira_set_weight_planes')
+
+    @property
+    def weight_planes(self) -> int:
+        v = C.c_int(0)
+        self._ck(self._lib.ira_get_weight_planes(self._h, C.byref(v)), 'ira_get_weight_planes')
+        return v.value
 
     def set_ffn_generation(self, gen: int):
         self._ck(self._lib.ira_set_ffn_generation(self._h, int(gen)), 'ira_set_ffn_generation')
@@ -229,11 +236,10 @@ class RestormerBackend(_Backend):
 
     def __init__(self, cfg: RestormerConfig, state_dict, device: int = 0, weight_planes: int = 1):
         """``weight_planes``: 1 (default) = the 1x1 layers of the levels with 192 / 384 channels (levels 3-4 of the agent's presets) run on
-        plain fp16 weights, 2 = hi + lo planes everywhere (ira_set_weight_planes; it cannot be switched back to 2 on the same handle)."""
+        plain fp16 weights - what ira_model_create itself leaves the handle in -, 2 = hi + lo planes everywhere (ira_set_weight_planes)."""
         self.cfg = cfg
         self._create(device, 'ira_model_create', _cfg_struct(cfg), pack_blob(state_dict, cfg), 'ira_model_create')
-        if weight_planes != 2:
-            self.set_weight_planes(weight_planes)
+        self.set_weight_planes(weight_planes)
 
 
 class NAFNetBackend(_Backend):
@@ -286,13 +292,12 @@ class SwinIRBackend(_Backend):
     def __init__(self, cfg, state_dict, device: int = 0, weight_planes: int = 1):
         """``weight_planes``: 1 (default) = the transformer layers' 1x1s run on plain fp16 weights (the lo planes are zeroed in the handle;
         frame-sized launches of K = 192 / 256 layers skip them), 2 = hi + lo planes everywhere.  Measured on the reference-generated goldens
-        and at the benchmark geometry against the oracle: |dPSNR| <= 6e-5 dB.  Cannot be switched back to 2 on the same handle."""
+        and at the benchmark geometry against the oracle: |dPSNR| <= 6e-5 dB.  1 is also the state ira_swinir_create leaves."""
         from .swinir import pack_swinir_blob, swinir_cfg_struct
         self.cfg = cfg
         self.scale = cfg.upscale
         self._create(device, 'ira_swinir_create', swinir_cfg_struct(cfg), pack_swinir_blob(state_dict, cfg), 'ira_swinir_create')
-        if weight_planes != 2:
-            self.set_weight_planes(weight_planes)
+        self.set_weight_planes(weight_planes)
 
 
 class XRestormerBackend(_Backend):
@@ -304,5 +309,4 @@ class XRestormerBackend(_Backend):
         self.cfg = cfg
         self.scale = cfg.scale
         self._create(device, 'ira_xrestormer_create', xrestormer_cfg_struct(cfg), pack_xrestormer_blob(state_dict, cfg), 'ira_xrestormer_create')
-        if weight_planes != 2:
-            self.set_weight_planes(weight_planes)       # levels 3-4 (C = 192 / 384) on plain fp16 weights, as RestormerBackend
+        self.set_weight_planes(weight_planes)       # 1: levels 3-4 (C = 192 / 384) on plain fp16 weights, as RestormerBackend

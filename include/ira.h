@@ -396,14 +396,16 @@ int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void
  * after a separate apply kernel.  For A/B measurements; also settable with the environment variable IRA_FFN_GEN at create time. */
 int ira_set_ffn_generation(ira_model_t* m, int gen);
 
-/* Weight precision of the LayerNorm-fed and residual 1x1 layers.  2 (the state after create) = every weight as fp16 hi + lo planes (two
- * MFMAs per fragment, ~fp32-exact weights).  1 = plain fp16 weights (the hi plane alone) in the layers that have a kernel for it: the
- * transformer 1x1s of a SwinIR handle; qkv / project_in / project_out / attention apply of the Restormer and X-Restormer levels with
- * C = 192 / 384 (levels 3-4 of the agent's presets).  The call ZEROES the lo planes of those weights in the handle's copy of the blob, so
- * that launches too small for the hi-plane kernels give the same numbers (a result never depends on the launch batch); it therefore
- * cannot be undone on the same handle (2 after 1 is an error).  Other architectures ignore it.  Measured: SwinIR-L x4 at the
- * benchmark geometry |dPSNR| 6e-5 dB, 149.6 -> 132.8 ms; Restormer 4K frame: emulator 69.4 -> 69.1 dB against the oracle, 235.6 -> 229.1 ms. */
+/* Weight precision of the LayerNorm-fed and residual 1x1 layers.  1 = plain fp16 weights (the hi plane alone) in the layers that have a
+ * kernel for it: the transformer 1x1s of a SwinIR handle; qkv / project_in / project_out / attention apply of the Restormer and X-Restormer
+ * levels with C = 192 / 384 (levels 3-4 of the agent's presets).  2 = every weight as fp16 hi + lo planes (two MFMAs per fragment, ~fp32-exact
+ * weights).  **The state after create is 1 for Restormer, X-Restormer and SwinIR handles** (the product default, the same for C and Python
+ * callers; the other architectures have no hi-plane kernels and ignore the setting).  With 1 the lo planes of those weights are ZEROED in the
+ * handle's copy of the blob (after a device-side backup), so that launches too small for the hi-plane kernels give the same numbers (a result
+ * never depends on the launch batch); 2 copies the backup back.  Measured: SwinIR-L x4 at the benchmark geometry |dPSNR| 6e-5
+ * dB, 149.6 -> 132.8 ms; Restormer 4K frame: emulator 69.4 -> 69.1 dB against the oracle, 235.6 -> 229.1 ms. */
 int ira_set_weight_planes(ira_model_t* m, int planes);
+int ira_get_weight_planes(ira_model_t* m, int* planes);
 
 /* Fused attention front end: LN + qkv 1x1 + depthwise 3x3 (restormer_arch.py:105-106,114) in one kernel; C in {48, 96}.
  * x fp32 NHWC (T,H,W,C); Wq packed qkv weights (LN gain folded, hi/lo, fragment-major), bq fp32 or NULL; dww fp32

@@ -56,7 +56,18 @@ def test_restormer_40_tiles_one_launch(restormer4k):
     assert torch.isfinite(t40).all()
     assert torch.equal(t40, t2), f"{int((t40 != t2).sum())} elements differ between the 40-tile launch and 2-tile launches"
     del t2
+    # ONE tile per launch: level 3 then has 128 x 128 = 16 384 pixels, below the 32 768 of pw_wide_supported / nres_wide_supported, so the
+    # deep levels run on the narrow kernels (k_pw_kres_lds / k_pw_nres_lds / k_pw_gemm) while the 40- and 2-tile launches above both take
+    # the wide ones: a service call with a single tile and a small per-rank shard must give the same bits as the frame launch
+    Hp, Wp, th, tw, nr, nc = __import__('ira_amd._capi', fromlist=['tile_plan']).tile_plan(H4K, W4K, TILE, OVERLAP)
+    be.set_max_batch(1)
+    for first in (0, 11, 38):
+        t1 = torch.empty(2, th, tw, 3, dtype=torch.float32, device='cuda')
+        be.restore_tiles_device(frame.data_ptr(), H4K, W4K, 3, TILE, OVERLAP, first, 2, t1.data_ptr())
+        be.sync()
+        assert torch.equal(t1, t40[first:first + 2]), f"tiles {first}, {first + 1}: {int((t1 != t40[first:first + 2]).sum())} elements differ between one-tile launches (narrow deep-level kernels) and the 40-tile launch"
     be.set_max_batch(64)
+    assert be.weight_planes == 1           # the product default of the handle (C and Python agree: ira_model_create leaves 1)
 
     # (b) the blend kernel on the 40 tiles against the reference loop on the CPU
     out = torch.empty(H4K, W4K, 3, dtype=torch.uint8, device='cuda')

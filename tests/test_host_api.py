@@ -322,3 +322,28 @@ def test_mprnet_tool_contract(tmp_path):
         tool(other, _empty(tmp_path / 'out_c'), silent=True)
     from ira_amd.mprnet import task_config
     assert (task_config('Deraining').n_feat, task_config('Deraining').scale_orsnetfeats) == (40, 16)
+
+
+def test_missing_rccl_is_an_error_not_a_crash(tmp_path):
+    """with librccl.so not loadable the first ira_comm_* call must return IRA_ERR_COMM with a message (it used to
+    build a std::string from a second, NULL dlerror() and crash).  IRA_RCCL_LIB names the one library the loader tries."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ira_amd import _capi\n"
+        "lib = _capi.load_library()\n"
+        "buf = (C.c_ubyte * 128)()\n"
+        "rc = lib.ira_comm_unique_id(buf)\n"
+        "lib.ira_last_error.restype = C.c_char_p\n"
+        "msg = lib.ira_last_error(None).decode()\n"
+        "print(rc, '|', msg)\n"
+        "assert rc == 6, rc\n"
+        "assert 'cannot load librccl.so' in msg and 'no-such-dir' in msg, msg\n"
+        "rc2 = lib.ira_comm_unique_id(buf)\n"
+        "assert rc2 == 6\n"
+    ) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'image-restoration-agent_amd')
+    env = dict(os.environ, IRA_RCCL_LIB=str(tmp_path / 'no-such-dir' / 'librccl.so'))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
