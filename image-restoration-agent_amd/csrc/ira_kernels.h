@@ -50,6 +50,14 @@ hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, c
 bool qkv_fused_supported(int C);
 hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq,
                             const float* dww, const float* dwb, void* qk, void* v, int T, int H, int W);
+// Second generation (ira_qkv2.hip): persistent workgroups, halo rows of the next patch requested under the current patch's main loop,
+// transposed 1x1 so that the depthwise conv's lanes own whole pixel-minor q,k elements.  Same arguments, layouts and bits.
+// launch_qkv_front picks the generation: 2 unless IRA_QKV_GEN=1 (A/B on the same box; read once per process).
+hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                            const float* dwb, void* qk, void* v, int T, int H, int W);
+bool qkv2_supported(int C);
+hipError_t launch_qkv2(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                       const float* dwb, void* qk, void* v, int T, int H, int W);
 
 // Fused GDFN (ira_ffn_fused.hip): x_out = x + ffn(LN(x)); x_out must not alias x.  Supported for C in {48, 96}.
 bool ffn_fused_supported(int C, int Hp);

@@ -305,7 +305,7 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
         char kq[64];
         if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
-        RUN(m, kq, ira::launch_qkv_fused(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
+        RUN(m, kq, ira::launch_qkv_front(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
     } else {
         RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P, 1e-5f, 0, 0, hi_plane_level(C) ? m->w_planes : 2));
         RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));

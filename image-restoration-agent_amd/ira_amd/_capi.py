@@ -130,6 +130,7 @@ SIGNATURES = {
     'ira_set_weight_planes': (_i, [_vp, _i]),
     'ira_get_weight_planes': (_i, [_vp, _vp]),
     'ira_op_qkv_fused': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    'ira_op_qkv_fused_gen': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'ira_set_fused_ffn': (_i, [_vp, _i]),
     'ira_op_embed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     'ira_op_concat2': (_i, [_vp, _vp, _i, _vp, _i, _vp, _l]),

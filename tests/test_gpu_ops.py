@@ -619,9 +619,13 @@ def test_ffn2_matches_generation_1(ctx):
     (96, 1, 1, 16, 64, False),
     (96, 2, 2, 9, 37, True),        # WithBias LN + biases; W % 8 = 5: zero-padded pixel-minor rows
     (48, 2, 1, 8, 33, False),       # W % 8 = 1
+    (96, 1, 3, 40, 100, False),     # 60 patches, interior ones (the fast halo-row path of generation 2) and every kind of border
+    (48, 1, 2, 24, 96, True),
 ])
-def test_qkv_fused(ctx, C, ln, T, H, W, bias):
-    """LN + qkv 1x1 + depthwise 3x3 in one kernel (restormer_arch.py:105-106,114) against the fp32 torch ops."""
+@pytest.mark.parametrize('gen', [1, 2])
+def test_qkv_fused(ctx, C, ln, T, H, W, bias, gen):
+    """LN + qkv 1x1 + depthwise 3x3 in one kernel (restormer_arch.py:105-106,114) against the fp32 torch ops; both kernel generations
+    (1: ira_qkv_fused.hip, 2: the persistent ira_qkv2.hip that the network schedule runs)."""
     from ira_amd.config import RestormerConfig
     from ira_amd.pack import pack_block
     from oracle import restormer_oracle as O
@@ -658,9 +662,59 @@ def test_qkv_fused(ctx, C, ln, T, H, W, bias):
     WB = (W + 7) // 8
     qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
     v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
-    rc = ctx._lib.ira_op_qkv_fused(ctx.handle, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
-                                   ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
+    rc = ctx._lib.ira_op_qkv_fused_gen(ctx.handle, gen, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
+                                       ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
     assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
     # fp16 LN output and fp16 1x1 output inside: a few fp16 ulps of the intermediate magnitudes
     close(v.cpu().float(), v_ref, 4e-3, 3e-3)
     close(qk.cpu().float(), q_ref, 4e-3, 3e-3)
+
+
+@pytest.mark.parametrize('C,ln,T,H,W,bias', [
+    (96, 1, 4, 96, 224, False),     # 336 patches: more than one per CU (the persistent loop of generation 2), all interior / border kinds
+    (48, 2, 5, 72, 230, True),      # 360 patches, ragged right edge (W % 32 = 6, W % 8 = 6), WithBias LN + biases
+    (96, 2, 1, 17, 41, True),
+    (48, 1, 1, 512, 512, False),    # one benchmark tile at level 1 (1024 patches)
+])
+def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias):
+    """The persistent second-generation kernel makes the same products in the same order as generation 1: q,k and v are bit-identical
+    (and generation 1 is the one checked against torch above and, through the network fixtures, against the reference)."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    g = torch.Generator().manual_seed(7 * C + ln + W)
+    hid = 32
+    sd = {
+        'b.norm1.body.weight': 1 + 0.1 * torch.randn(C, generator=g), 'b.norm2.body.weight': torch.ones(C),
+        'b.attn.temperature': torch.ones(1, 1, 1), 'b.attn.qkv.weight': torch.randn(3 * C, C, 1, 1, generator=g) / C ** 0.5,
+        'b.attn.qkv_dwconv.weight': torch.randn(3 * C, 1, 3, 3, generator=g) / 3,
+        'b.attn.project_out.weight': torch.zeros(C, C, 1, 1),
+        'b.ffn.project_in.weight': torch.zeros(2 * hid, C, 1, 1), 'b.ffn.dwconv.weight': torch.zeros(2 * hid, 1, 3, 3),
+        'b.ffn.project_out.weight': torch.zeros(C, hid, 1, 1),
+    }
+    if ln == 2:
+        sd['b.norm1.body.bias'] = 0.1 * torch.randn(C, generator=g)
+        sd['b.norm2.body.bias'] = torch.zeros(C)
+    if bias:
+        for k, n in [('attn.qkv', 3 * C), ('attn.qkv_dwconv', 3 * C), ('attn.project_out', C), ('ffn.project_in', 2 * hid),
+                     ('ffn.dwconv', 2 * hid), ('ffn.project_out', C)]:
+            sd[f'b.{k}.bias'] = 0.1 * torch.randn(n, generator=g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree' if ln == 1 else 'WithBias', bias=bias)
+    cfg.hidden = lambda d_: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
+    xd = (torch.randn(T, H, W, C, generator=g) * 1.5).cuda()
+    WB = (W + 7) // 8
+    outs = []
+    for gen in (1, 2):
+        qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
+        v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
+        for rep in range(2 if gen == 2 else 1):        # generation 2 twice: a persistent kernel must not depend on what the last launch left
+            rc = ctx._lib.ira_op_qkv_fused_gen(ctx.handle, gen, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
+                                               ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
+            assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+        torch.cuda.synchronize()
+        outs.append((qk, v))
+    assert torch.isfinite(outs[0][0].float()).all() and torch.isfinite(outs[0][1].float()).all()
+    nq = int((outs[0][0].view(torch.int16) != outs[1][0].view(torch.int16)).sum()); nv = int((outs[0][1].view(torch.int16) != outs[1][1].view(torch.int16)).sum())
+    assert nq == 0 and nv == 0, f"{nq} q,k and {nv} v elements differ between the two generations"

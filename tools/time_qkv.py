@@ -7,7 +7,8 @@ from ira_amd.config import reduced_config, RestormerConfig
 from ira_amd.weights import seeded_state_dict
 from ira_amd.pack import pack_block
 cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2")))
-Cc, hid, T, H, W = 96, 32, 8, 512, 512
+Cc, hid, T, H, W = int(os.environ.get('QC', '96')), 32, int(os.environ.get('QT', '8')), 512, 512
+GEN = int(os.environ.get('GEN', '2'))
 g = torch.Generator().manual_seed(0)
 sd = {'b.norm1.body.weight': torch.ones(Cc), 'b.norm2.body.weight': torch.ones(Cc), 'b.attn.temperature': torch.ones(1, 1, 1),
       'b.attn.qkv.weight': torch.randn(3 * Cc, Cc, 1, 1, generator=g) / Cc ** 0.5, 'b.attn.qkv_dwconv.weight': torch.randn(3 * Cc, 1, 3, 3, generator=g) / 3,
@@ -20,10 +21,10 @@ x = torch.randn(T, H, W, Cc, generator=g).cuda()
 qk = torch.empty(T, H, W // 8, 2 * Cc, 8, dtype=torch.float16, device='cuda'); v = torch.empty(T, H, W, Cc, dtype=torch.float16, device='cuda')
 p = lambda t: C.c_void_p(t.data_ptr())
 def run():
-    rc = be._lib.ira_op_qkv_fused(be.handle, p(x), 1, Cc, p(d['b.qkv_w']), None, p(d['b.dw1_w']), None, p(qk), p(v), T, H, W); assert rc == 0
+    rc = be._lib.ira_op_qkv_fused_gen(be.handle, GEN, p(x), 1, Cc, p(d['b.qkv_w']), None, p(d['b.dw1_w']), None, p(qk), p(v), T, H, W); assert rc == 0
 run(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): run()
-torch.cuda.synchronize(); print('qkv_fused C=96 T8: %.3f ms' % ((time.perf_counter() - t0) * 100))
+torch.cuda.synchronize(); print('qkv_fused gen %d C=%d T=%d: %.3f ms' % (GEN, Cc, T, (time.perf_counter() - t0) * 100))
 if os.environ.get('IRA_HIP_LIB', '').endswith('stamps.so'):
     buf = (C.c_ulonglong * 128)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv_stamps(buf) == 0
     prod = [buf[i] for i in range(64)]; cons = [buf[64 + i] for i in range(64)]; t0 = min(prod[0], cons[0])
