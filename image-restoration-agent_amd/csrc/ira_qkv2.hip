@@ -24,20 +24,23 @@
 //     w N/4 + 64 it + lane in iteration it; for a patch inside the image the global address of an iteration is a wave-uniform base + 16 lane).
 // LDS (C = 96): x staging 8 160 pieces = 130 560 B (overlaid by the two hidden buffers, 2 x 25 616 B, and the transposition
 // scratch, 4 x 1 280 B, while the main loop runs) + weights / biases 12.7 KB = 143.3 KB: one workgroup per CU, eight waves.
-// Barriers per patch: 3 + number of chunks (C = 96: 12).  Numerics: bit-identical to generation 1 (same products in the same order:
-// tests/test_gpu_ops.py::test_qkv2_equals_generation1).
+// Barriers per patch: 3 + number of chunks (C = 96: 12).  Numerics: the rounding points and products of generation 1; the transposed MFMA
+// forms its fp32 sums in another order, so about 6e-6 of the fp16 hidden values land on the other neighbour (measured; everything else is
+// bit-identical: tests/test_gpu_ops.py::test_qkv2_equals_generation1).  Deterministic, and a patch's result does not depend on the launch.
 #include "ira_kernels.h"
 #include "ira_device.h"
 
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace ira {
 
 namespace {
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;                  // 10 x 34 halo patch
+constexpr int NWP = 8, NWC = 8, NTHR = 64 * (NWP + NWC);                    // waves 0-7: LayerNorm + 1x1 (P); waves 8-15: halo rows, depthwise 3x3, stores (C)
 constexpr int NG = 11;                                                      // 8 interior rows + top row + bottom row + the two halo columns
 constexpr int RS = 40;                                                      // halfs per (halo row, channel) record: 32 interior pixels, [32] right halo, [39] left halo of the NEXT record
 constexpr int REC0 = 8;                                                     // halfs in front of record 0 (so that record 0 has a left-halo slot)
@@ -72,12 +75,12 @@ template <int C> struct Q2 {
     static constexpr int PP = C / 4;                                        // 16-byte pieces per pixel
     static constexpr int PPR = PW * PP;                                     // ... per halo row
     static constexpr int NPIECE = PH * PPR;
-    static constexpr int PERW = NPIECE / 4;                                 // ... per C wave: 2.5 halo rows
+    static constexpr int PERW = NPIECE / NWC;                               // ... per C wave: 1.25 halo rows
     static constexpr int NIT = (PERW + 63) / 64;                            // ... per C-wave thread
     static constexpr int SH = (C == 96) ? 3 : 2;                            // swizzle shift (found by enumeration: tools/lds_swizzle_search.py)
     static constexpr size_t STG_BYTES = (((size_t)NPIECE + 15) / 16 * 16) * 16;
-    static_assert(NPIECE % 4 == 0 && (PERW * 2) % PPR == 0, "a C wave owns 2.5 halo rows");
-    static constexpr size_t MAIN_BYTES = 2 * HPT_BYTES + 4 * SCR_BYTES;
+    static_assert(NPIECE % NWC == 0 && (PERW * 4) % PPR == 0 && PPR % 4 == 0, "a C wave owns 1.25 halo rows");
+    static constexpr size_t MAIN_BYTES = 2 * HPT_BYTES + NWC * SCR_BYTES;
     static constexpr size_t DYN_BYTES = STG_BYTES > MAIN_BYTES ? STG_BYTES : MAIN_BYTES;
     static constexpr size_t WDW_BYTES = (size_t)NCH * 9 * 32 * 4;
     static constexpr size_t B_BYTES = (size_t)NCH * 32 * 4;
@@ -87,8 +90,23 @@ template <int C> struct Q2 {
 
 }  // namespace
 
+#ifdef IRA_KERNEL_DBG
+__device__ unsigned long long g_qkv2_stamps[2][64];     // [P wave 0 / C wave 8][event] of workgroup 17 (make dbg; tools/time_qkv.py)
+#define QSTAMP(role) do { if (blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == NWP) && stamp_n < 64) g_qkv2_stamps[role][stamp_n] = __builtin_amdgcn_s_memtime(); ++stamp_n; } while (0)
+#else
+#define QSTAMP(role) do {} while (0)
+#endif
+// Measurement variants (wrong results): 1 no global stores, 2 no halo-row loads, 4 no MFMAs, 8 no depthwise FMAs.  Compiled only with
+// -DIRA_KERNEL_DBG_FLAGS (not part of `make dbg`: the one build that had them faulted on the GPU and the cause was not found).
+#ifdef IRA_KERNEL_DBG_FLAGS
+__device__ int g_qkv2_dbg;
+#define QDBG(bit) (g_dbg & (bit))
+#else
+#define QDBG(bit) false
+#endif
+
 template <int C, int LN, bool BIN, bool CB>
-__global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const f16* __restrict__ Wq, const float* __restrict__ bq,
+__global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, const f16* __restrict__ Wq, const float* __restrict__ bq,
                                               const float* __restrict__ dww, const float* __restrict__ dwb, f16* __restrict__ qk,
                                               f16* __restrict__ vout, int T, int H, int W, long NP) {
     using G = Q2<C>;
@@ -106,14 +124,18 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
     const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
     const int WB = (W + 7) >> 3;
     const long G_ = gridDim.x;
+    [[maybe_unused]] int stamp_n = 0;
+#ifdef IRA_KERNEL_DBG_FLAGS
+    const int g_dbg = __builtin_amdgcn_readfirstlane(g_qkv2_dbg);
+#endif
 
     // ---- once per workgroup: depthwise weights / biases in the lane order of the transposed product (column c = channel 32 j + rowperm(c))
-    for (int i = tid; i < NCH * 9 * 32; i += 512) {
+    for (int i = tid; i < NCH * 9 * 32; i += NTHR) {
         const int j = i / 288, rem = i - j * 288, tap = rem >> 5, cc = rem & 31;
         const int ch = 32 * j + rowperm(cc);
         wdw[i] = ch < NQ ? dww[(long)tap * NQ + ch] : 0.f;
     }
-    for (int i = tid; i < NCH * 32; i += 512) {
+    for (int i = tid; i < NCH * 32; i += NTHR) {
         const int ch = 32 * (i >> 5) + rowperm(i & 31);
         bdw[i] = (CB && ch < NQ) ? dwb[ch] : 0.f;
         b1[i] = (BIN && ch < NQ) ? bq[ch] : 0.f;
@@ -126,33 +148,38 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
         x0 = (int)(pid % npx) * TW;
     };
 
-    if (wave < 4) {
+    if (wave < NWP) {
         // ========================================================================= P waves: LayerNorm + transposed 1x1
         const long w_lo = (long)NCH * KS * 1024;       // bytes between the hi and the lo plane
         const unsigned lane16 = lane * 16;             // a fragment = 64 lanes x 16 bytes: wave-uniform base (scalar registers) + this
-        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-        const int ngroups = (wave + 8 < NG) ? 3 : 2;
+        using S0 = std::integral_constant<int, 0>;
+        const int ngroups = (wave + NWP < NG) ? 2 : 1;     // groups wave and wave + 8 (waves 0-2)
         const int pr = rowperm(c);                     // A row c of a group holds pixel rowperm(c): see header
         for (long vb = blockIdx.x; vb < NP; vb += G_) {
             int t, y0, x0;
             coords(vb, t, y0, x0);
             const bool inside = y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W;       // the whole halo patch lies in the image
             // (declared per patch: nothing of them is live across the patch loop's back edge)
-            half8 xa[3][KS];                           // A fragments (pixels x k) of this wave's groups wave, wave + 4, wave + 8
-            half8 wh[2][KS], wl[2][KS];                // B fragments (weights, hi / lo planes) of this chunk / the next one
+            half8 xa[2][KS];                           // A fragments (pixels x k) of this wave's groups wave, wave + 8
+            half8 wh[1][KS], wl[1][KS];                // B fragments (weights, hi / lo planes) of one chunk: the next chunk's are requested into the
+                                                       // same registers right behind the last MFMA (four waves per SIMD cover the latency; 128 registers per wave)
             auto load_w = [&](int j, auto SETc) {
                 constexpr int set = decltype(SETc)::value;
                 const char* w = (const char*)Wq + (long)j * KS * 1024;
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16));          // scalar base + this one register: as loop invariants the twelve per-lane addresses were kept (and spilled)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) { wh[set][s] = *(const half8*)(w + s * 1024 + lane16); wl[set][s] = *(const half8*)(w + w_lo + s * 1024 + lane16); }
+                for (int s = 0; s < KS; ++s) { wh[set][s] = *(const half8*)(w + s * 1024 + l16); wl[set][s] = *(const half8*)(w + w_lo + s * 1024 + l16); }
             };
+            QSTAMP(0);
             lds_barrier();                             // B0: the previous patch's units are done with the hidden buffers
-            load_w(0, S0{});
+            QSTAMP(0);
             lds_barrier();                             // B1: the staging area holds this patch
+            QSTAMP(0);
 #pragma unroll
-            for (int gi = 0; gi < 3; ++gi) {
+            for (int gi = 0; gi < 2; ++gi) {
                 if (gi >= ngroups) break;
-                int q = group_px(wave + 4 * gi, pr);
+                int q = group_px(wave + NWP * gi, pr);
                 q = q < 0 ? 0 : q;
                 asm volatile("" : "+v"(q));            // recompute the LDS addresses per patch: hoisted out of the patch loop they would cost 36 registers
                 const int n0 = q * G::PP + 2 * h;      // first piece of this lane's 8 channels of k-step 0
@@ -187,7 +214,10 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                     xa[gi][s] = o;
                 }
             }
+            load_w(0, S0{});                           // (requested here, not before the LayerNorm: 48 more live registers there meant spills)
+            QSTAMP(0);
             lds_barrier();                             // B2: every P wave has its pixels: the staging area becomes the hidden buffers
+            QSTAMP(0);
 
             auto produce = [&](int j, auto SETc) {
                 constexpr int set = decltype(SETc)::value;
@@ -196,14 +226,15 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                 asm volatile("" : "+v"(lofs));         // addresses are rebuilt from one register per call: as loop invariants they were kept in ~40 (spilled)
                 const float bias = BIN ? b1[32 * j + c] : 0.f;
 #pragma unroll
-                for (int gi = 0; gi < 3; ++gi) {
+                for (int gi = 0; gi < 2; ++gi) {
                     if (gi >= ngroups) break;
-                    const int g = wave + 4 * gi;
+                    const int g = wave + NWP * gi;
                     f32x16 acc;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = bias;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
+                        if (QDBG(4)) { asm volatile("" :: "v"(xa[gi][s]), "v"(wh[set][s]), "v"(wl[set][s])); continue; }
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wh[set][s], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wl[set][s], acc, 0, 0, 0);
                     }
@@ -255,75 +286,91 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                 }
             };
 #pragma unroll 1
-            for (int j = 0; j < NCH; j += 2) {
-                if (j + 1 < NCH) load_w(j + 1, S1{});
+            for (int j = 0; j < NCH; ++j) {
                 produce(j, S0{});
+                __builtin_amdgcn_sched_barrier(0);     // the requests below reuse the weight registers: they must stay behind the last MFMA
+                if (j + 1 < NCH) load_w(j + 1, S0{});
+                __builtin_amdgcn_sched_barrier(0);
+                QSTAMP(0);
                 lds_barrier();
-                if (j + 1 < NCH) {
-                    if (j + 2 < NCH) load_w(j + 2, S0{});
-                    produce(j + 1, S1{});
-                    lds_barrier();
-                }
+                QSTAMP(0);
             }
         }
         return;
     }
 
     // ============================================================================= C waves: halo rows of the next patch + depthwise 3x3 + stores
-    const int cw = wave - 4;
+    const int cw = wave - NWP;
     f32x4 piece[G::NIT];
-    const int par = cw & 1, hy_start = (5 * cw) >> 1;      // this wave's pieces start at halo row hy_start (+ half a row for odd waves)
-    // Patch inside the image: iteration it of this wave reads 64 consecutive pieces of a halo row (or the tail of one row and the head of
-    // the next): the address is a wave-uniform row base + 16 bytes per lane.  Everything but the lane term is scalar arithmetic.
-    auto prefetch_inside = [&](auto PARc, const float* row0, long wrow) {      // row0: first float of halo row hy_start, wrow: floats per image row
-        constexpr int PAR = decltype(PARc)::value, S0 = PAR * (G::PPR / 2);
-#pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            const int n0 = S0 + 64 * it, hy = n0 / G::PPR, wi0 = n0 - hy * G::PPR, thr = G::PPR - wi0;     // compile-time after unrolling
-            int ln = lane;
-            if (64 * it + 63 >= G::PERW) ln = ln < G::PERW - 1 - 64 * it ? ln : G::PERW - 1 - 64 * it;     // the last iteration is short (56 / 60 pieces): extra lanes repeat the last one
-            const float* b0 = row0 + hy * wrow + 4 * wi0;
-            if (thr >= 64) piece[it] = *(const f32x4*)(b0 + 4 * ln);
-            else {
-                const float* b1 = row0 + (hy + 1) * wrow - 4 * thr;
-                piece[it] = *(const f32x4*)((ln >= thr ? b1 : b0) + 4 * ln);
-            }
-        }
-    };
+    const int par = cw & 3, hy_start = (5 * cw) >> 2;      // this wave's pieces start at halo row hy_start, par quarter rows in
+    // The NEXT patch's pieces are requested ONE PER UNIT of the current patch's main loop (36 units for 32 pieces at C = 96): a wave cannot
+    // issue vector-memory instructions faster than the CU's share of HBM bandwidth drains them (~10 bytes per cycle: 130 KB in one burst kept the
+    // C waves at the issue for 13.7k cycles, measured), so the requests are spread over the whole patch and ride beside the stores.
+    // Patch inside the image: piece `it` of this wave = 64 consecutive pieces of a halo row (or the tail of one row and the head of the
+    // next): a wave-uniform row base + 16 bytes per lane; everything but the lane term is scalar arithmetic.
     // Patch at the image border: per-piece clamped coordinates (any finite values do: the hidden values of pixels outside the image are zeroed).
-    auto prefetch_border = [&](const float* xt, int y0, int x0) {
-        int nb = cw * G::PERW + lane;
-        asm volatile("" : "+v"(nb));                   // keep this path's per-piece arithmetic out of the patch loop's preheader (it would be kept in registers)
-#pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            int n = nb + 64 * it;
-            n = n < (cw + 1) * G::PERW ? n : (cw + 1) * G::PERW - 1;
-            const int hy = n / G::PPR, wi = n - hy * G::PPR, hx = wi / G::PP, chq = wi - hx * G::PP;
-            int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
-            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            piece[it] = *(const f32x4*)(xt + ((long)yy * W + xx) * C + 4 * chq);
-        }
-    };
-    auto prefetch = [&](long vb) {
+    struct Next { const float* xt; const float* row0; long wrow; int y0, x0; bool inside, any; } nx{};
+    auto set_next = [&](long vb) {
+        nx.any = vb < NP;
+        if (!nx.any) return;
         int t, y0, x0;
         coords(vb, t, y0, x0);
-        const float* xt = x + (long)t * H * W * C;
-        const bool inside = y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W;
-        if (inside) {
-            const float* row0 = xt + ((long)(y0 - 1 + hy_start) * W + (x0 - 1)) * C;
-            if (par) prefetch_inside(std::integral_constant<int, 1>{}, row0, (long)W * C);
-            else prefetch_inside(std::integral_constant<int, 0>{}, row0, (long)W * C);
-        } else prefetch_border(xt, y0, x0);
+        nx.xt = x + (long)t * H * W * C;
+        nx.y0 = y0; nx.x0 = x0;
+        nx.inside = y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W;
+        nx.row0 = nx.xt + ((long)(y0 - 1 + hy_start) * W + (x0 - 1)) * C;
+        nx.wrow = (long)W * C;
+    };
+    auto fetch_inside = [&](auto PARc, auto ITc) {
+        constexpr int PAR = decltype(PARc)::value, it = decltype(ITc)::value, S0 = PAR * (G::PPR / 4);
+        constexpr int n0 = S0 + 64 * it, hy = n0 / G::PPR, wi0 = n0 - hy * G::PPR, thr = G::PPR - wi0;
+        int ln = lane;
+        if (64 * it + 63 >= G::PERW) ln = ln < G::PERW - 1 - 64 * it ? ln : G::PERW - 1 - 64 * it;     // the last piece is short (56 / 60 lanes): extra lanes repeat the last one
+        const float* b0 = nx.row0 + hy * nx.wrow + 4 * wi0;
+        if (thr >= 64) piece[it] = *(const f32x4*)(b0 + 4 * ln);
+        else {
+            const float* b1 = nx.row0 + (hy + 1) * nx.wrow - 4 * thr;
+            piece[it] = *(const f32x4*)((ln >= thr ? b1 : b0) + 4 * ln);
+        }
+    };
+    auto fetch_border = [&](auto ITc) {
+        constexpr int it = decltype(ITc)::value;
+        int n = cw * G::PERW + lane + 64 * it;
+        asm volatile("" : "+v"(n));                    // (keeps this rarely used arithmetic from being hoisted out of the patch loop into registers)
+        n = n < (cw + 1) * G::PERW ? n : (cw + 1) * G::PERW - 1;
+        const int hy = n / G::PPR, wi = n - hy * G::PPR, hx = wi / G::PP, chq = wi - hx * G::PP;
+        int yy = nx.y0 - 1 + hy, xx = nx.x0 - 1 + hx;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        piece[it] = *(const f32x4*)(nx.xt + ((long)yy * W + xx) * C + 4 * chq);
+    };
+    auto fetch = [&](auto ITc) {
+        constexpr int it = decltype(ITc)::value;
+        if constexpr (it < G::NIT) {
+            if (!nx.any || QDBG(2)) return;
+            if (nx.inside) {
+                if (par == 0) fetch_inside(std::integral_constant<int, 0>{}, ITc);
+                else if (par == 1) fetch_inside(std::integral_constant<int, 1>{}, ITc);
+                else if (par == 2) fetch_inside(std::integral_constant<int, 2>{}, ITc);
+                else fetch_inside(std::integral_constant<int, 3>{}, ITc);
+            } else fetch_border(ITc);
+        }
+    };
+    auto fetch_all_from = [&](auto FROMc) {            // pieces FROM .. NIT-1 (all of them before the first patch; the rest after the last unit)
+        constexpr int from = decltype(FROMc)::value;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (fetch(std::integral_constant<int, from + I>{}), ...); }(std::make_integer_sequence<int, (G::NIT > from ? G::NIT - from : 0)>{});
     };
     f16* scr = scr_all + (size_t)cw * (SCR_BYTES / 2);                     // this wave's transposition scratch
-    prefetch(blockIdx.x);
+    set_next(blockIdx.x);
+    fetch_all_from(std::integral_constant<int, 0>{});
     for (long vb = blockIdx.x; vb < NP; vb += G_) {
         int t, y0, x0;
         coords(vb, t, y0, x0);
+        QSTAMP(1);
         lds_barrier();                                 // B0
+        QSTAMP(1);
         {
-            int nb = cw * G::PERW + lane;              // linear piece index of iteration 0 (halo row * PPR + piece of the row)
+            int nb = cw * G::PERW + lane;              // linear piece index of piece 0 (halo row * PPR + piece of the row)
             asm volatile("" : "+v"(nb));
 #pragma unroll
             for (int it = 0; it < G::NIT; ++it) {
@@ -331,21 +378,26 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                 if (64 * it + 63 < G::PERW || n < (cw + 1) * G::PERW) xs[n ^ ((n >> G::SH) & 15)] = piece[it];
             }
         }
+        QSTAMP(1);
         lds_barrier();                                 // B1
-        if (vb + G_ < NP) prefetch(vb + G_);
+        QSTAMP(1);
+        set_next(vb + G_);
+        QSTAMP(1);
         lds_barrier();                                 // B2
         lds_barrier();                                 // interval 0: the P waves produce chunk 0
-#pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
+        QSTAMP(1);
+        auto chunk = [&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
             const f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
             float wv[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) wv[k] = wdw[(j * 9 + k) * 32 + c];
             const float bias = CB ? bdw[32 * j + c] : 0.f;
             const int ch = 32 * j + rowperm(c);
-#pragma unroll
-            for (int ui = 0; ui < 4; ++ui) {
-                const int u = 4 * cw + ui;             // unit = (patch row, half row): this wave's four units are rows 2cw, 2cw + 1
+            auto unit = [&](auto UIc) {
+                constexpr int ui = decltype(UIc)::value;
+                fetch(std::integral_constant<int, 2 * j + ui>{});          // one piece of the next patch per unit
+                const int u = 2 * cw + ui;             // unit = (patch row, half row): this wave's two units are the halves of patch row cw
                 const int ry = u >> 1, b = 2 * (u & 1) + h;
                 const int oy = y0 + ry;
                 float acc[8];
@@ -363,6 +415,7 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
                             const int e = p + dx - 1;
+                            if (QDBG(8)) { asm volatile("" :: "v"(m), "v"(lft), "v"(rgt)); continue; }
                             if (e < 0) fma_mix_hi(acc[p], lft[1], w);
                             else if (e == 8) fma_mix_lo(acc[p], rgt[0], w);
                             else if (e & 1) fma_mix_hi(acc[p], m[e >> 1], w);
@@ -371,10 +424,10 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                     }
                 }
                 const int ox = x0 + 8 * b;
-                if (j < G::NQK) {
+                if constexpr (j < G::NQK) {
                     // q / k: the lane's 8 pixels of channel ch are one element of the pixel-minor tensor.  Rows are padded to WB * 8 pixels and the
                     // padding must read as zero for the Gram: store every block below WB * 8, zeros for x >= W
-                    if (oy < H && ox < WB * 8) {
+                    if (oy < H && ox < WB * 8 && !QDBG(1)) {
                         u32x4 o;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -394,15 +447,29 @@ __global__ __launch_bounds__(512) void k_qkv2(const float* __restrict__ x, const
                     const int p16 = lane >> 2, o8 = lane & 3;
                     const u32x4 o = *(const u32x4*)(scr + p16 * SCR_STRIDE + 8 * o8);
                     const int vx = x0 + 16 * (u & 1) + p16, vch = 32 * j - 2 * C + 8 * o8;
-                    if (oy < H && vx < W && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
+                    if (oy < H && vx < W && vch < C && !QDBG(1)) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                 }
-            }
-            if (j + 1 < NCH) lds_barrier();            // (the last interval's barrier is B0 of the next patch)
-        }
+            };
+            unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
+            if constexpr (j + 1 == NCH) fetch_all_from(std::integral_constant<int, 2 * NCH>{});      // (none left: 16 pieces for 18 units at C = 96, 8 for 10 at C = 48)
+            QSTAMP(1);
+            if constexpr (j + 1 < NCH) lds_barrier();  // (the last interval's barrier is B0 of the next patch)
+            QSTAMP(1);
+        };
+        [&]<int... J>(std::integer_sequence<int, J...>) { (chunk(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NCH>{});
     }
 }
+
+#ifdef IRA_KERNEL_DBG
+#ifdef IRA_KERNEL_DBG_FLAGS
+extern "C" int ira_debug_qkv2_flags(int flags) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qkv2_dbg), &flags, sizeof flags); }
+#endif
+extern "C" int ira_debug_qkv2_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qkv2_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 bool qkv2_supported(int C) { return C == 48 || C == 96; }
 
@@ -424,7 +491,7 @@ static hipError_t qkv2_launch2(hipStream_t st, const float* x, const f16* Wq, co
     // the workgroup walks (xcd_swizzle keys on the low three bits)
     long grid = NP < ncu ? NP : ncu;
     if (grid >= 8) grid &= ~7L;
-    hipLaunchKernelGGL((k_qkv2<C, LN, BIN, CB>), dim3((unsigned)grid), dim3(512), Q2<C>::LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W, NP);
+    hipLaunchKernelGGL((k_qkv2<C, LN, BIN, CB>), dim3((unsigned)grid), dim3(NTHR), Q2<C>::LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W, NP);
     return hipGetLastError();
 }
 

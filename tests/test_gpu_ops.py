@@ -677,8 +677,11 @@ def test_qkv_fused(ctx, C, ln, T, H, W, bias, gen):
     (48, 1, 1, 512, 512, False),    # one benchmark tile at level 1 (1024 patches)
 ])
 def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias):
-    """The persistent second-generation kernel makes the same products in the same order as generation 1: q,k and v are bit-identical
-    (and generation 1 is the one checked against torch above and, through the network fixtures, against the reference)."""
+    """The persistent second-generation kernel has the same rounding points as generation 1 (fp16 LayerNorm output, fp16 1x1 output, fp32
+    depthwise sums, fp16 results) and forms the same products; the only difference is that its 1x1 is the TRANSPOSED MFMA (pixels as rows),
+    whose fp32 sums are formed in another order.  Measured: about 6e-6 of the hidden values land on the other fp16 neighbour (each
+    reaches the 3 x 3 outputs around it); everything else is bit-identical.  Asserted: differing outputs < 1e-3 of all, each by at most one
+    fp16 ulp of the 1x1 output's magnitude scaled by the depthwise weight, and generation 2 is deterministic from launch to launch."""
     from ira_amd.config import RestormerConfig
     from ira_amd.pack import pack_block
     g = torch.Generator().manual_seed(7 * C + ln + W)
@@ -706,15 +709,20 @@ def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias):
     xd = (torch.randn(T, H, W, C, generator=g) * 1.5).cuda()
     WB = (W + 7) // 8
     outs = []
-    for gen in (1, 2):
+    for gen in (1, 2, 2):                              # generation 2 twice, into fresh buffers: a persistent kernel must not depend on what the last launch left
         qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
         v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
-        for rep in range(2 if gen == 2 else 1):        # generation 2 twice: a persistent kernel must not depend on what the last launch left
-            rc = ctx._lib.ira_op_qkv_fused_gen(ctx.handle, gen, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
-                                               ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
-            assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+        rc = ctx._lib.ira_op_qkv_fused_gen(ctx.handle, gen, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),
+                                           ptr(d.get('b.dw1_b')), ptr(qk), ptr(v), T, H, W)
+        assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
         torch.cuda.synchronize()
         outs.append((qk, v))
-    assert torch.isfinite(outs[0][0].float()).all() and torch.isfinite(outs[0][1].float()).all()
-    nq = int((outs[0][0].view(torch.int16) != outs[1][0].view(torch.int16)).sum()); nv = int((outs[0][1].view(torch.int16) != outs[1][1].view(torch.int16)).sum())
-    assert nq == 0 and nv == 0, f"{nq} q,k and {nv} v elements differ between the two generations"
+    for k, name in ((0, 'q,k'), (1, 'v')):
+        a, b, b2 = outs[0][k], outs[1][k], outs[2][k]
+        assert torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all()
+        assert torch.equal(b.view(torch.int16), b2.view(torch.int16)), f"{name}: generation 2 differs from launch to launch"
+        df = (a.float() - b.float()).abs()
+        ndiff = int((df > 0).sum())
+        # one fp16 ulp of a hidden value of magnitude < 8 is 2^-8 at most; a depthwise weight is < 2 here
+        print(f"{name}: {ndiff} of {a.numel()} elements differ, max |delta| {float(df.max()):.3e}")
+        assert ndiff < 1e-3 * a.numel() and float(df.max()) <= 2 ** -7, (name, ndiff, float(df.max()))
