@@ -55,6 +55,9 @@ hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, 
 // launch_qkv_front picks the generation: 2 unless IRA_QKV_GEN=1 (A/B on the same box; read once per process).
 hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                             const float* dwb, void* qk, void* v, int T, int H, int W);
+bool qkv3_supported(int C);
+hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                       const float* dwb, void* qk, void* v, int T, int H, int W);
 bool qkv2_supported(int C);
 hipError_t launch_qkv2(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                        const float* dwb, void* qk, void* v, int T, int H, int W);

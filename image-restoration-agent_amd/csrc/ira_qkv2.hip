@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
         b1[i] = (BIN && ch < NQ) ? bq[ch] : 0.f;
     }
 
-    auto coords = [&](long vb, int& t, int& y0, int& x0) {
+    auto coords = [&](long vb, int& t, int& y0, int& x0) __attribute__((always_inline)) {
         const long pid = xcd_swizzle(vb, NP);
         t = (int)(pid / ((long)npy * npx));
         y0 = (int)((pid / npx) % npy) * TH;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             half8 xa[2][KS];                           // A fragments (pixels x k) of this wave's groups wave, wave + 8
             half8 wh[1][KS], wl[1][KS];                // B fragments (weights, hi / lo planes) of one chunk: the next chunk's are requested into the
                                                        // same registers right behind the last MFMA (four waves per SIMD cover the latency; 128 registers per wave)
-            auto load_w = [&](int j, auto SETc) {
+            auto load_w = [&](int j, auto SETc) __attribute__((always_inline)) {
                 constexpr int set = decltype(SETc)::value;
                 const char* w = (const char*)Wq + (long)j * KS * 1024;
                 unsigned l16 = lane16;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             lds_barrier();                             // B2: every P wave has its pixels: the staging area becomes the hidden buffers
             QSTAMP(0);
 
-            auto produce = [&](int j, auto SETc) {
+            auto produce = [&](int j, auto SETc) __attribute__((always_inline)) {
                 constexpr int set = decltype(SETc)::value;
                 f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
                 int lofs = c * RS + 8 * h;             // this lane's slot inside a halo row's block of records (halfs)
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
                         f16* bA = col - 1 + (h ? 8 * ROWH : 0);
                         f16* bB = h ? col + 32 - 2 * ROWH : col - 1;
                         f16* bC = col + 32 + 6 * ROWH;
-                        auto val = [&](int e, int hy, bool right) -> f16 {
+                        auto val = [&](int e, int hy, bool right) __attribute__((always_inline)) -> f16 {
                             const int yy = y0 - 1 + hy, xx = right ? x0 + TW : x0 - 1;
                             const bool ok = inside || (yy >= 0 && yy < H && xx >= 0 && xx < W);
                             return ok ? (f16)acc[e] : (f16)0.f;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
     // next): a wave-uniform row base + 16 bytes per lane; everything but the lane term is scalar arithmetic.
     // Patch at the image border: per-piece clamped coordinates (any finite values do: the hidden values of pixels outside the image are zeroed).
     struct Next { const float* xt; const float* row0; long wrow; int y0, x0; bool inside, any; } nx{};
-    auto set_next = [&](long vb) {
+    auto set_next = [&](long vb) __attribute__((always_inline)) {
         nx.any = vb < NP;
         if (!nx.any) return;
         int t, y0, x0;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
         nx.row0 = nx.xt + ((long)(y0 - 1 + hy_start) * W + (x0 - 1)) * C;
         nx.wrow = (long)W * C;
     };
-    auto fetch_inside = [&](auto PARc, auto ITc) {
+    auto fetch_inside = [&](auto PARc, auto ITc) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PARc)::value, it = decltype(ITc)::value, S0 = PAR * (G::PPR / 4);
         constexpr int n0 = S0 + 64 * it, hy = n0 / G::PPR, wi0 = n0 - hy * G::PPR, thr = G::PPR - wi0;
         int ln = lane;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             piece[it] = *(const f32x4*)((ln >= thr ? b1 : b0) + 4 * ln);
         }
     };
-    auto fetch_border = [&](auto ITc) {
+    auto fetch_border = [&](auto ITc) __attribute__((always_inline)) {
         constexpr int it = decltype(ITc)::value;
         int n = cw * G::PERW + lane + 64 * it;
         asm volatile("" : "+v"(n));                    // (keeps this rarely used arithmetic from being hoisted out of the patch loop into registers)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
         xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
         piece[it] = *(const f32x4*)(nx.xt + ((long)yy * W + xx) * C + 4 * chq);
     };
-    auto fetch = [&](auto ITc) {
+    auto fetch = [&](auto ITc) __attribute__((always_inline)) {
         constexpr int it = decltype(ITc)::value;
         if constexpr (it < G::NIT) {
             if (!nx.any || QDBG(2)) return;
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             } else fetch_border(ITc);
         }
     };
-    auto fetch_all_from = [&](auto FROMc) {            // pieces FROM .. NIT-1 (all of them before the first patch; the rest after the last unit)
+    auto fetch_all_from = [&](auto FROMc) __attribute__((always_inline)) {            // pieces FROM .. NIT-1 (all of them before the first patch; the rest after the last unit)
         constexpr int from = decltype(FROMc)::value;
-        [&]<int... I>(std::integer_sequence<int, I...>) { (fetch(std::integral_constant<int, from + I>{}), ...); }(std::make_integer_sequence<int, (G::NIT > from ? G::NIT - from : 0)>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (fetch(std::integral_constant<int, from + I>{}), ...); }(std::make_integer_sequence<int, (G::NIT > from ? G::NIT - from : 0)>{});
     };
     f16* scr = scr_all + (size_t)cw * (SCR_BYTES / 2);                     // this wave's transposition scratch
     set_next(blockIdx.x);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
         lds_barrier();                                 // B2
         lds_barrier();                                 // interval 0: the P waves produce chunk 0
         QSTAMP(1);
-        auto chunk = [&](auto Jc) {
+        auto chunk = [&](auto Jc) __attribute__((always_inline)) {
             constexpr int j = decltype(Jc)::value;
             const f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
             float wv[9];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             for (int k = 0; k < 9; ++k) wv[k] = wdw[(j * 9 + k) * 32 + c];
             const float bias = CB ? bdw[32 * j + c] : 0.f;
             const int ch = 32 * j + rowperm(c);
-            auto unit = [&](auto UIc) {
+            auto unit = [&](auto UIc) __attribute__((always_inline)) {
                 constexpr int ui = decltype(UIc)::value;
                 fetch(std::integral_constant<int, 2 * j + ui>{});          // one piece of the next patch per unit
                 const int u = 2 * cw + ui;             // unit = (patch row, half row): this wave's two units are the halves of patch row cw
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NTHR) void k_qkv2(const float* __restrict__ x, cons
             if constexpr (j + 1 < NCH) lds_barrier();  // (the last interval's barrier is B0 of the next patch)
             QSTAMP(1);
         };
-        [&]<int... J>(std::integer_sequence<int, J...>) { (chunk(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NCH>{});
+        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (chunk(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NCH>{});
     }
 }
 
@@ -518,8 +518,9 @@ hipError_t launch_qkv2(hipStream_t st, const float* x, int ln_mode, int C, const
 
 hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                             const float* dwb, void* qk, void* v, int T, int H, int W) {
-    static const int gen = getenv("IRA_QKV_GEN") ? atoi(getenv("IRA_QKV_GEN")) : 2;
+    static const int gen = getenv("IRA_QKV_GEN") ? atoi(getenv("IRA_QKV_GEN")) : 3;
     if (gen == 1) return launch_qkv_fused(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
+    if (gen == 3) return launch_qkv3(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
     return launch_qkv2(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
 }
 

@@ -1,0 +1,375 @@
+// Fused attention front end, third generation (restormer_arch.py:114 after :146's norm1):
+//     qkv = dwconv3x3( conv1x1( LN(x) ) )            q,k -> fp16 pixel-minor [T][H][ceil(W/8)][2C][8], v -> fp16 NHWC
+// Same contract, layouts and rounding points as ira_qkv_fused.hip (generation 1) and ira_qkv2.hip (generation 2).
+//
+// What the first two measured: a CU's share of HBM bandwidth is ~10 bytes per cycle, a patch moves 277 KB (28k cycles), and
+// both generations take 51-64k cycles per patch because ONE workgroup per CU walks through its phases in series: while it waits for its
+// halo patch nothing computes, while it computes nothing is in flight, and any wave that issues loads under the main loop stalls AT THE
+// ISSUE for as long as the memory pipeline is backed up (generation 2: 13.7k cycles for 32 requests).  The remedy is the ordinary one:
+// TWO workgroups per CU, each small and simple, so that one's memory phase lies under the other's arithmetic:
+//   * a workgroup = 4 waves = one 8 x 32 output patch (10 x 34 halo = 11 pixel groups); at most 256 registers and 69 KB of LDS, two per CU;
+//   * no roles.  Wave w loads the pixels of its groups w, w + 4, w + 8 straight into registers, LayerNorms them (statistics over a lane
+//     pair) and keeps them as MFMA A fragments for the whole kernel (pixel-stationary: no LDS round trip, no barrier before the first MFMA);
+//   * the 1x1 runs TRANSPOSED (generation 2): D[pixel][channel] = LN(x) . W, the packed weight fragments are the B operand as they are, and
+//     with the row permutation applied to a group's PIXELS a lane of the result owns two runs of 8 consecutive pixels of one channel.  The
+//     hidden tile goes to LDS as [halo row][channel][pixel] (two ds_write_b128 per lane and group), double buffered, one barrier per chunk;
+//   * the depthwise 3x3 runs on lanes = (channel, 8-pixel block): per halo row one ds_read_b128 and two ds_read_b64 (the left halo column
+//     sits in the last slot of the previous record, so both neighbours are plain offsets), 72 v_fma_mix_f32 with the lane's nine weights in
+//     registers, and the 8 results ARE one 16-byte element of the pixel-minor q,k tensor (one store per lane, 512 consecutive bytes per 32
+//     lanes).  v chunks go through a 1.25 KB per-wave LDS transposition and are stored as 16-byte pieces of 8 channels;
+//   * every wave runs the chunk's MFMAs for its groups AND four of its sixteen depthwise units; chunk j + 1's MFMAs and chunk j's units
+//     are independent instruction streams of the same wave (the vector work issues in the shadow of the MFMAs), and the other workgroup's
+//     waves on the same SIMDs fill what is left.
+// LDS: hidden buffers 2 x 25 616 B + transposition scratch 4 x 1 280 B = 56.4 KB.
+#include "ira_kernels.h"
+#include "ira_device.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace ira {
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;                  // 10 x 34 halo patch
+constexpr int NW = 4;                                                       // waves per workgroup
+constexpr int NG = 11;                                                      // 8 interior rows + top row + bottom row + the two halo columns
+constexpr int RS = 40;                                                      // halfs per (halo row, channel) record: 32 interior pixels, [32] right halo, [39] left halo of the NEXT record
+constexpr int REC0 = 8;                                                     // halfs in front of record 0 (so that record 0 has a left-halo slot)
+constexpr size_t HPT_BYTES = (size_t)(REC0 + PH * 32 * RS) * 2;             // 25 616 B (a multiple of 16)
+constexpr int SCR_STRIDE = 40;                                              // halfs per pixel row of the v transposition scratch
+constexpr size_t SCR_BYTES = (size_t)16 * SCR_STRIDE * 2;                   // 1 280 B per wave
+constexpr size_t Q3_LDS = 2 * HPT_BYTES + NW * SCR_BYTES;
+static_assert(HPT_BYTES % 16 == 0, "hidden buffers must keep 16-byte alignment");
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+IRA_DEV unsigned pack2(float lo, float hi) {
+    typedef f16 half2v __attribute__((ext_vector_type(2)));
+    half2v t; t[0] = (f16)lo; t[1] = (f16)hi;
+    return __builtin_bit_cast(unsigned, t);
+}
+
+// (halo row, halo column) of pixel p of group g; hy < 0 for the padding of the last group
+IRA_DEV void group_px(int g, int p, int& hy, int& hx) {
+    if (g < TH) { hy = g + 1; hx = 1 + p; }
+    else if (g == TH) { hy = 0; hx = 1 + p; }
+    else if (g == TH + 1) { hy = PH - 1; hx = 1 + p; }
+    else if (p < PH) { hy = p; hx = 0; }
+    else if (p < 2 * PH) { hy = p - PH; hx = PW - 1; }
+    else { hy = -1; hx = 0; }
+}
+
+template <int N> using IC = std::integral_constant<int, N>;
+
+}  // namespace
+
+#ifdef IRA_KERNEL_DBG
+__device__ unsigned long long g_qkv3_stamps[64];        // s_memtime of wave 0 of workgroup 1777 (make dbg; tools/time_qkv.py)
+#define Q3STAMP() do { if (blockIdx.x == 1777 && tid == 0 && stamp_n < 64) g_qkv3_stamps[stamp_n] = __builtin_amdgcn_s_memtime(); ++stamp_n; } while (0)
+#else
+#define Q3STAMP() do {} while (0)
+#endif
+
+template <int C, int LN, bool BIN, bool CB>
+__global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x, const f16* __restrict__ Wq, const float* __restrict__ bq,
+                                                     const float* __restrict__ dww, const float* __restrict__ dwb, f16* __restrict__ qk,
+                                                     f16* __restrict__ vout, int T, int H, int W) {
+    constexpr int KS = C / 16, NQ = 3 * C, NCH = (NQ + 31) / 32, NQK = 2 * C / 32;
+    static_assert(2 * C % 32 == 0, "a chunk is either q,k or v");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* hpb = (f16*)smem;                                                  // [2] hidden buffers, see header
+    f16* scr_all = (f16*)(smem + 2 * HPT_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npy = (H + TH - 1) / TH, npx = (W + TW - 1) / TW;
+    const int WB = (W + 7) >> 3;
+    const long pid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int t = (int)(pid / ((long)npy * npx));
+    const int y0 = (int)((pid / npx) % npy) * TH, x0 = (int)(pid % npx) * TW;
+    const float* xt = x + (long)t * H * W * C;
+    const bool inside = y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W;       // the whole halo patch lies in the image
+    const int ngroups = (wave + 2 * NW < NG) ? 3 : 2;
+    [[maybe_unused]] int stamp_n = 0;
+    Q3STAMP();
+    const int chl = rowperm(c);                        // column c of the transposed product is channel 32 j + rowperm(c) (the packed weights' row order)
+
+    // ---- weights of chunk j: MFMA B fragments (hi / lo planes), a wave-uniform base + 16 bytes per lane; depthwise weights / biases of this lane's channel
+    half8 wh[1][KS], wl[1][KS];
+    float wv[2][9], bias1[1], biasd[2];
+    const long w_lo = (long)NCH * KS * 1024;           // bytes between the hi and the lo plane
+    auto load_w = [&](int j, auto SETc) __attribute__((always_inline)) {
+        constexpr int set = decltype(SETc)::value;
+        const char* w = (const char*)Wq + (long)j * KS * 1024;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { wh[set][s] = *(const half8*)(w + s * 1024 + lane * 16); wl[set][s] = *(const half8*)(w + w_lo + s * 1024 + lane * 16); }
+        const int ch = 32 * j + chl;
+        const int chc = ch < NQ ? ch : NQ - 1;
+        bias1[set] = (BIN && ch < NQ) ? bq[chc] : 0.f;
+    };
+    auto load_dw = [&](int j, auto SETc) __attribute__((always_inline)) {
+        constexpr int set = decltype(SETc)::value;
+        const int ch = 32 * j + chl;
+        const int chc = ch < NQ ? ch : NQ - 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const float w = dww[(long)k * NQ + chc]; wv[set][k] = ch < NQ ? w : 0.f; }
+        biasd[set] = (CB && ch < NQ) ? dwb[chc] : 0.f;
+    };
+
+    // ---- prologue: this wave's pixels -> LayerNorm -> A fragments (A row c of a group holds pixel rowperm(c))
+    half8 xa[3][KS];
+    {
+        f32x4 xlo[3][KS], xhi[3][KS];
+        auto request = [&](auto GIc) __attribute__((always_inline)) {
+            constexpr int gi = decltype(GIc)::value;
+            int hy, hx;
+            group_px(wave + NW * gi, chl, hy, hx);
+            int yy = y0 - 1 + (hy < 0 ? 0 : hy), xx = x0 - 1 + hx;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);                      // pixels outside the image: any finite values (their hidden values are zeroed)
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const float* src = xt + ((long)yy * W + xx) * C + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { xlo[gi][s] = *(const f32x4*)(src + 16 * s); xhi[gi][s] = *(const f32x4*)(src + 16 * s + 4); }
+        };
+        auto normalise = [&](auto GIc) __attribute__((always_inline)) {
+            constexpr int gi = decltype(GIc)::value;
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += xlo[gi][s][j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += xhi[gi][s][j];
+            }
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xlo[gi][s][j] - mu; sq += d * d; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = xhi[gi][s][j] - mu; sq += d * d; }
+            }
+            sq += __shfl_xor(sq, 32);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+            const float sub = (LN == 2) ? mu : 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (f16)((xlo[gi][s][j] - sub) * rstd); o[4 + j] = (f16)((xhi[gi][s][j] - sub) * rstd); }
+                xa[gi][s] = o;
+            }
+        };
+        request(IC<0>{}); request(IC<1>{});
+        Q3STAMP();
+        normalise(IC<0>{});
+        Q3STAMP();
+        __builtin_amdgcn_sched_barrier(0);             // (the third group's 48 registers are the first group's: at most two groups of raw pixels are live)
+        if (ngroups > 2) request(IC<2>{});
+        load_w(0, IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        normalise(IC<1>{});
+        if (ngroups > 2) normalise(IC<2>{});
+        Q3STAMP();
+    }
+
+    // ---- the 1x1 of chunk j on this wave's groups -> hidden buffer j & 1
+    auto produce = [&](int j, auto SETc, auto INc) __attribute__((always_inline)) {
+        constexpr int set = decltype(SETc)::value;
+        constexpr bool inside = decltype(INc)::value;  // compile-time here: a patch inside the image carries no masks at all
+        f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
+        const int lofs = c * RS + 8 * h;               // this lane's slot inside a halo row's block of records (halfs)
+        const float bias = bias1[set];
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            if (gi == 2 && ngroups < 3) continue;
+            const int g = wave + NW * gi;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = bias;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wh[set][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wl[set][s], acc, 0, 0, 0);
+            }
+            if (g < NG - 1) {
+                // a halo row's 32 interior pixels: this lane owns pixels 8h .. 8h+7 (registers 0-7) and 16+8h .. 16+8h+7 (8-15) of its channel
+                const int hy = g < TH ? g + 1 : (g == TH ? 0 : PH - 1);
+                u32x4 o1, o2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o1[k] = pack2(acc[2 * k], acc[2 * k + 1]); o2[k] = pack2(acc[8 + 2 * k], acc[8 + 2 * k + 1]); }
+                if constexpr (!inside) {
+                    // zero padding of the depthwise conv: pixels outside the image hold zeros, whatever the 1x1 (and its bias) made of them
+                    const int yy = y0 - 1 + hy;
+                    const bool rowok = yy >= 0 && yy < H;
+                    const int n1 = rowok ? W - x0 - 8 * h : 0, n2 = rowok ? W - x0 - 16 - 8 * h : 0;      // valid pixels of the two runs
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o1[k] &= (2 * k < n1 ? 0xFFFFu : 0u) | (2 * k + 1 < n1 ? 0xFFFF0000u : 0u);
+                        o2[k] &= (2 * k < n2 ? 0xFFFFu : 0u) | (2 * k + 1 < n2 ? 0xFFFF0000u : 0u);
+                    }
+                }
+                f16* rec = hp + REC0 + hy * 32 * RS + lofs;
+                *(u32x4*)rec = o1;
+                *(u32x4*)(rec + 16) = o2;
+            } else {
+                // the two halo columns.  Group pixel p < 10 = left column (slot -1 of the record) of halo row p, p < 20 = right column (slot 32)
+                // of halo row p - 10; a lane holds p = 8h + e (registers e = 0..7) and 16 + 8h + e (8..15):
+                //   e = 0, 1:  h = 0: left rows 0, 1          h = 1: left rows 8, 9
+                //   e = 2..7:  h = 0: left rows 2..7          h = 1: right rows 0..5
+                //   e = 8..11: h = 0: right rows 6..9         h = 1: nothing (p >= 24)
+                constexpr int ROWH = 32 * RS;                  // halfs per halo row
+                f16* col = hp + REC0 + (lofs - 8 * h);         // record (halo row 0, this lane's channel)
+                f16* bA = col - 1 + (h ? 8 * ROWH : 0);
+                f16* bB = h ? col + 32 - 2 * ROWH : col - 1;
+                f16* bC = col + 32 + 6 * ROWH;
+                auto val = [&](int e, int hy, bool right) __attribute__((always_inline)) -> f16 {
+                    const int yy = y0 - 1 + hy, xx = right ? x0 + TW : x0 - 1;
+                    const bool ok = inside || (yy >= 0 && yy < H && xx >= 0 && xx < W);
+                    return ok ? (f16)acc[e] : (f16)0.f;
+                };
+#pragma unroll
+                for (int e = 0; e < 2; ++e) bA[e * ROWH] = val(e, e + 8 * h, false);
+#pragma unroll
+                for (int e = 2; e < 8; ++e) bB[e * ROWH] = val(e, h ? e - 2 : e, h != 0);
+                if (h == 0) {
+#pragma unroll
+                    for (int e = 8; e < 12; ++e) bC[(e - 8) * ROWH] = val(e, e - 2, true);
+                }
+            }
+        }
+    };
+
+    // ---- depthwise 3x3 of chunk j: this wave's four units = the two halves of patch rows 2 wave, 2 wave + 1
+    f16* scr = scr_all + (size_t)wave * (SCR_BYTES / 2);
+    auto units = [&](auto Jc, auto SETc, auto INc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value, set = decltype(SETc)::value;
+        constexpr bool inside = decltype(INc)::value;
+        const f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
+        const int ch = 32 * j + chl;
+#pragma unroll
+        for (int ui = 0; ui < 4; ++ui) {
+            const int ry = 2 * wave + (ui >> 1), b = 2 * (ui & 1) + h;
+            const int oy = y0 + ry;
+            float acc[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = biasd[set];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const f16* rec = hp + REC0 + ((ry + dy) * 32 + c) * RS + 8 * b;
+                const u32x4 m = *(const u32x4*)rec;
+                const u32x2 lft = *(const u32x2*)(rec - 4), rgt = *(const u32x2*)(rec + 8);
+                // element e of the row segment (e = -1 .. 8): -1 = lft[1] high half, 0..7 = m, 8 = rgt[0] low half
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float w = wv[set][dy * 3 + dx];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const int e = p + dx - 1;
+                        if (e < 0) fma_mix_hi(acc[p], lft[1], w);
+                        else if (e == 8) fma_mix_lo(acc[p], rgt[0], w);
+                        else if (e & 1) fma_mix_hi(acc[p], m[e >> 1], w);
+                        else fma_mix_lo(acc[p], m[e >> 1], w);
+                    }
+                }
+            }
+            const int ox = x0 + 8 * b;
+            if constexpr (j < NQK) {
+                // q / k: the lane's 8 pixels of channel ch are one element of the pixel-minor tensor.  Rows are padded to WB * 8 pixels and the
+                // padding must read as zero for the Gram: store every block below WB * 8, zeros for x >= W
+                if (inside || (oy < H && ox < WB * 8)) {
+                    u32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = (inside || ox + 2 * k < W) ? acc[2 * k] : 0.f, hi = (inside || ox + 2 * k + 1 < W) ? acc[2 * k + 1] : 0.f;
+                        o[k] = pack2(lo, hi);
+                    }
+                    *(u32x4*)(qk + ((((long)t * H + oy) * WB + (ox >> 3)) * (2 * C) + ch) * 8) = o;
+                }
+            } else {
+                // v (NHWC): transpose the wave's 16 pixels x 32 channels through LDS, then 16-byte pieces of 8 channels of one pixel
+#pragma unroll
+                for (int p = 0; p < 8; ++p) scr[(8 * h + p) * SCR_STRIDE + chl] = (f16)acc[p];
+                // the read below takes what OTHER lanes of this wave wrote: LDS operations of one wave execute in order, the compiler
+                // must not move the read above the writes
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int p16 = lane >> 2, o8 = lane & 3;
+                const u32x4 o = *(const u32x4*)(scr + p16 * SCR_STRIDE + 8 * o8);
+                const int vx = x0 + 16 * (ui & 1) + p16, vch = 32 * j - 2 * C + 8 * o8;
+                if ((inside || (oy < H && vx < W)) && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+
+    // ---- main loop: interval j = chunk j's 1x1 (into buffer j & 1) + chunk j-1's depthwise units (out of buffer (j-1) & 1); one barrier per interval.
+    // Weight sets alternate with the chunk parity; chunk j + 1's fragments and depthwise weights are requested at the top of interval j.
+    auto run = [&](auto INc) __attribute__((always_inline)) {
+        auto interval = [&](auto Jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(Jc)::value;         // 0 .. NCH
+            if constexpr (j < NCH) produce(j, IC<0>{}, INc);
+            // chunk j + 1's weight fragments are requested INTO THE SAME REGISTERS, behind the last MFMA that reads them: they arrive under this
+            // interval's depthwise units.  (Requested at the top of the interval into a second set they were 48 more live registers: spills.)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j + 1 < NCH) load_w(j + 1, IC<0>{});
+            if constexpr (j < NCH) load_dw(j, IC<j & 1>{});                     // (used by the units of the NEXT interval)
+            __builtin_amdgcn_sched_barrier(0);
+            Q3STAMP();
+            if constexpr (j > 0) units(IC<(j > 0 ? j - 1 : 0)>{}, IC<((j > 0 ? j - 1 : 0)) & 1>{}, INc);
+            Q3STAMP();
+            if constexpr (j < NCH) lds_barrier();
+            Q3STAMP();
+        };
+        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (interval(IC<J>{}), ...); }(std::make_integer_sequence<int, NCH + 1>{});
+    };
+    if (inside) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+#ifdef IRA_KERNEL_DBG
+extern "C" int ira_debug_qkv3_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qkv3_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
+bool qkv3_supported(int C) { return C == 48 || C == 96; }
+
+template <int C, int LN, bool BIN, bool CB>
+static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww, const float* dwb, f16* qk,
+                               f16* v, int T, int H, int W) {
+    const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, Q3_LDS, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), Q3_LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    return hipGetLastError();
+}
+
+template <int C>
+static hipError_t qkv3_launch(hipStream_t st, const float* x, int ln_mode, const f16* Wq, const float* bq, const float* dww, const float* dwb,
+                              f16* qk, f16* v, int T, int H, int W) {
+#define IRA_QKV3(LN_, BIN_, CB_) return qkv3_launch2<C, LN_, BIN_, CB_>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W)
+    if (ln_mode == 1) {
+        if (bq) { if (dwb) IRA_QKV3(1, true, true); else IRA_QKV3(1, true, false); }
+        else { if (dwb) IRA_QKV3(1, false, true); else IRA_QKV3(1, false, false); }
+    } else {
+        if (bq) { if (dwb) IRA_QKV3(2, true, true); else IRA_QKV3(2, true, false); }
+        else { if (dwb) IRA_QKV3(2, false, true); else IRA_QKV3(2, false, false); }
+    }
+#undef IRA_QKV3
+}
+
+hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                       const float* dwb, void* qk, void* v, int T, int H, int W) {
+    if ((ln_mode != 1 && ln_mode != 2) || !qkv3_supported(C)) return hipErrorInvalidValue;
+    if (C == 48) return qkv3_launch<48>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+    return qkv3_launch<96>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+}
+
+}  // namespace ira

@@ -622,7 +622,7 @@ def test_ffn2_matches_generation_1(ctx):
     (96, 1, 3, 40, 100, False),     # 60 patches, interior ones (the fast halo-row path of generation 2) and every kind of border
     (48, 1, 2, 24, 96, True),
 ])
-@pytest.mark.parametrize('gen', [1, 2])
+@pytest.mark.parametrize('gen', [1, 2, 3])
 def test_qkv_fused(ctx, C, ln, T, H, W, bias, gen):
     """LN + qkv 1x1 + depthwise 3x3 in one kernel (restormer_arch.py:105-106,114) against the fp32 torch ops; both kernel generations
     (1: ira_qkv_fused.hip, 2: the persistent ira_qkv2.hip that the network schedule runs)."""
@@ -676,7 +676,8 @@ def test_qkv_fused(ctx, C, ln, T, H, W, bias, gen):
     (96, 2, 1, 17, 41, True),
     (48, 1, 1, 512, 512, False),    # one benchmark tile at level 1 (1024 patches)
 ])
-def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias):
+@pytest.mark.parametrize('GEN_NEW', [2, 3])
+def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias, GEN_NEW):
     """The persistent second-generation kernel has the same rounding points as generation 1 (fp16 LayerNorm output, fp16 1x1 output, fp32
     depthwise sums, fp16 results) and forms the same products; the only difference is that its 1x1 is the TRANSPOSED MFMA (pixels as rows),
     whose fp32 sums are formed in another order.  Measured: about 6e-6 of the hidden values land on the other fp16 neighbour (each
@@ -709,7 +710,7 @@ def test_qkv2_equals_generation1(ctx, C, ln, T, H, W, bias):
     xd = (torch.randn(T, H, W, C, generator=g) * 1.5).cuda()
     WB = (W + 7) // 8
     outs = []
-    for gen in (1, 2, 2):                              # generation 2 twice, into fresh buffers: a persistent kernel must not depend on what the last launch left
+    for gen in (1, GEN_NEW, GEN_NEW):                  # the new generation twice, into fresh buffers: a persistent kernel must not depend on what the last launch left
         qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
         v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
         rc = ctx._lib.ira_op_qkv_fused_gen(ctx.handle, gen, ptr(xd), ln, C, ptr(d['b.qkv_w']), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']),

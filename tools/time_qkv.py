@@ -8,7 +8,7 @@ from ira_amd.weights import seeded_state_dict
 from ira_amd.pack import pack_block
 cfg0 = reduced_config(); be = RestormerBackend(cfg0, seeded_state_dict(cfg0, 1), weight_planes=int(os.environ.get("PLANES", "2")))
 Cc, hid, T, H, W = int(os.environ.get('QC', '96')), 32, int(os.environ.get('QT', '8')), 512, 512
-GEN = int(os.environ.get('GEN', '2'))
+GEN = int(os.environ.get('GEN', '3'))
 g = torch.Generator().manual_seed(0)
 sd = {'b.norm1.body.weight': torch.ones(Cc), 'b.norm2.body.weight': torch.ones(Cc), 'b.attn.temperature': torch.ones(1, 1, 1),
       'b.attn.qkv.weight': torch.randn(3 * Cc, Cc, 1, 1, generator=g) / Cc ** 0.5, 'b.attn.qkv_dwconv.weight': torch.randn(3 * Cc, 1, 3, 3, generator=g) / 3,
@@ -27,6 +27,11 @@ def run():
 run(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize(); print('qkv_fused gen %d C=%d T=%d dbg=%s: %.3f ms' % (GEN, Cc, T, os.environ.get('QDBG', '0'), (time.perf_counter() - t0) * 100))
+if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 3:
+    buf = (C.c_ulonglong * 64)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv3_stamps(buf) == 0
+    st = [int(buf[i] - buf[0]) for i in range(64)]
+    print('wave 0 of workgroup 1777: start, pixels + weights requested, group 0 normalised, all normalised, then per interval (1x1 done, units done, barrier passed):')
+    print('   ', st[:4], [tuple(st[4 + 3 * k: 7 + 3 * k]) for k in range(10)])
 if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 2:
     # make -C image-restoration-agent_amd/csrc dbg; IRA_HIP_LIB=.../libira_hip_dbg.so: s_memtime stamps of workgroup 17 (P wave 0, C wave 4), first patches
     buf = (C.c_ulonglong * 128)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv2_stamps(buf) == 0
