@@ -20,7 +20,8 @@
 //   * every wave runs the chunk's MFMAs for its groups AND four of its sixteen depthwise units; chunk j + 1's MFMAs and chunk j's units
 //     are independent instruction streams of the same wave (the vector work issues in the shadow of the MFMAs), and the other workgroup's
 //     waves on the same SIMDs fill what is left.
-// LDS: hidden buffers 2 x 25 616 B + transposition scratch 4 x 1 280 B = 56.4 KB.
+// LDS: hidden buffers 2 x 25 616 B + transposition scratch 4 x 1 280 B + two weight stages of 2 KS KB = 80 928 B at C = 96 (two
+// workgroups per CU: 2 x 81 920 B are there), 68 640 B at C = 48.
 #include "ira_kernels.h"
 #include "ira_device.h"
 
@@ -41,7 +42,7 @@ constexpr int REC0 = 8;                                                     // h
 constexpr size_t HPT_BYTES = (size_t)(REC0 + PH * 32 * RS) * 2;             // 25 616 B (a multiple of 16)
 constexpr int SCR_STRIDE = 40;                                              // halfs per pixel row of the v transposition scratch
 constexpr size_t SCR_BYTES = (size_t)16 * SCR_STRIDE * 2;                   // 1 280 B per wave
-constexpr size_t Q3_LDS = 2 * HPT_BYTES + NW * SCR_BYTES;
+constexpr size_t Q3_MAIN = 2 * HPT_BYTES + NW * SCR_BYTES;              // + two weight stages of 2 KS fragments (k_qkv3)
 static_assert(HPT_BYTES % 16 == 0, "hidden buffers must keep 16-byte alignment");
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -97,19 +98,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
     Q3STAMP();
     const int chl = rowperm(c);                        // column c of the transposed product is channel 32 j + rowperm(c) (the packed weights' row order)
 
-    // ---- weights of chunk j: MFMA B fragments (hi / lo planes), a wave-uniform base + 16 bytes per lane; depthwise weights / biases of this lane's channel
-    half8 wh[1][KS], wl[1][KS];
-    float wv[2][9], bias1[1], biasd[2];
-    const long w_lo = (long)NCH * KS * 1024;           // bytes between the hi and the lo plane
-    auto load_w = [&](int j, auto SETc) __attribute__((always_inline)) {
-        constexpr int set = decltype(SETc)::value;
-        const char* w = (const char*)Wq + (long)j * KS * 1024;
+    // ---- weights of chunk j: its 2 KS MFMA B fragments (hi plane, then lo plane; 1 KB each) travel L2 -> LDS by LDS-DMA, ONCE per workgroup
+    // (each wave moves its share), one interval ahead, into stage j & 1; every wave reads them from there, one ds_read_b128 per MFMA.  In
+    // registers (one private copy per wave, generation 1 / 2 and the first form of this kernel) they were 48 registers per set, four times
+    // the L2 traffic, and with a single set the request could only be issued behind the last MFMA: its latency (~5k cycles under load) lay open.
+    constexpr int NF = 2 * KS;
+    constexpr size_t WST = (size_t)NF * 1024;
+    char* wst = smem + Q3_MAIN;                        // [2][NF][64 lanes][16 B]
+    float bias1[2];
+    auto stage_w = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { wh[set][s] = *(const half8*)(w + s * 1024 + lane * 16); wl[set][s] = *(const half8*)(w + w_lo + s * 1024 + lane * 16); }
+        for (int i = 0; i < (NF + NW - 1) / NW; ++i) {
+            const int f = wave + NW * i;
+            if (f < NF) {
+                const int plane = f >= KS ? 1 : 0, sk = f - plane * KS;
+                const char* src = (const char*)Wq + ((long)plane * NCH * KS + (long)j * KS + sk) * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wst + (size_t)(j & 1) * WST + f * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto load_b1 = [&](int j, auto SETc) __attribute__((always_inline)) {
+        constexpr int set = decltype(SETc)::value;
         const int ch = 32 * j + chl;
         const int chc = ch < NQ ? ch : NQ - 1;
         bias1[set] = (BIN && ch < NQ) ? bq[chc] : 0.f;
     };
+    float wv[2][9], biasd[2];
     auto load_dw = [&](int j, auto SETc) __attribute__((always_inline)) {
         constexpr int set = decltype(SETc)::value;
         const int ch = 32 * j + chl;
@@ -165,172 +180,229 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
                 xa[gi][s] = o;
             }
         };
+        stage_w(0);
+        load_b1(0, IC<0>{});
         request(IC<0>{}); request(IC<1>{});
         Q3STAMP();
         normalise(IC<0>{});
         Q3STAMP();
         __builtin_amdgcn_sched_barrier(0);             // (the third group's 48 registers are the first group's: at most two groups of raw pixels are live)
         if (ngroups > 2) request(IC<2>{});
-        load_w(0, IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
         normalise(IC<1>{});
         if (ngroups > 2) normalise(IC<2>{});
         Q3STAMP();
     }
 
-    // ---- the 1x1 of chunk j on this wave's groups -> hidden buffer j & 1
-    auto produce = [&](int j, auto SETc, auto INc) __attribute__((always_inline)) {
-        constexpr int set = decltype(SETc)::value;
-        constexpr bool inside = decltype(INc)::value;  // compile-time here: a patch inside the image carries no masks at all
-        f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
-        const int lofs = c * RS + 8 * h;               // this lane's slot inside a halo row's block of records (halfs)
-        const float bias = bias1[set];
+    // wave 3 has two groups only; it runs a third, discarded one (a copy of its second) rather than branch around twelve MFMAs: the main loop
+    // is then the same straight-line code for every wave (only the few stores behind a group's MFMAs differ)
+    if (ngroups < 3) {
 #pragma unroll
-        for (int gi = 0; gi < 3; ++gi) {
-            if (gi == 2 && ngroups < 3) continue;
-            const int g = wave + NW * gi;
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = bias;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wh[set][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][s], wl[set][s], acc, 0, 0, 0);
-            }
-            if (g < NG - 1) {
-                // a halo row's 32 interior pixels: this lane owns pixels 8h .. 8h+7 (registers 0-7) and 16+8h .. 16+8h+7 (8-15) of its channel
-                const int hy = g < TH ? g + 1 : (g == TH ? 0 : PH - 1);
-                u32x4 o1, o2;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { o1[k] = pack2(acc[2 * k], acc[2 * k + 1]); o2[k] = pack2(acc[8 + 2 * k], acc[8 + 2 * k + 1]); }
-                if constexpr (!inside) {
-                    // zero padding of the depthwise conv: pixels outside the image hold zeros, whatever the 1x1 (and its bias) made of them
-                    const int yy = y0 - 1 + hy;
-                    const bool rowok = yy >= 0 && yy < H;
-                    const int n1 = rowok ? W - x0 - 8 * h : 0, n2 = rowok ? W - x0 - 16 - 8 * h : 0;      // valid pixels of the two runs
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        o1[k] &= (2 * k < n1 ? 0xFFFFu : 0u) | (2 * k + 1 < n1 ? 0xFFFF0000u : 0u);
-                        o2[k] &= (2 * k < n2 ? 0xFFFFu : 0u) | (2 * k + 1 < n2 ? 0xFFFF0000u : 0u);
-                    }
-                }
-                f16* rec = hp + REC0 + hy * 32 * RS + lofs;
-                *(u32x4*)rec = o1;
-                *(u32x4*)(rec + 16) = o2;
-            } else {
-                // the two halo columns.  Group pixel p < 10 = left column (slot -1 of the record) of halo row p, p < 20 = right column (slot 32)
-                // of halo row p - 10; a lane holds p = 8h + e (registers e = 0..7) and 16 + 8h + e (8..15):
-                //   e = 0, 1:  h = 0: left rows 0, 1          h = 1: left rows 8, 9
-                //   e = 2..7:  h = 0: left rows 2..7          h = 1: right rows 0..5
-                //   e = 8..11: h = 0: right rows 6..9         h = 1: nothing (p >= 24)
-                constexpr int ROWH = 32 * RS;                  // halfs per halo row
-                f16* col = hp + REC0 + (lofs - 8 * h);         // record (halo row 0, this lane's channel)
-                f16* bA = col - 1 + (h ? 8 * ROWH : 0);
-                f16* bB = h ? col + 32 - 2 * ROWH : col - 1;
-                f16* bC = col + 32 + 6 * ROWH;
-                auto val = [&](int e, int hy, bool right) __attribute__((always_inline)) -> f16 {
-                    const int yy = y0 - 1 + hy, xx = right ? x0 + TW : x0 - 1;
-                    const bool ok = inside || (yy >= 0 && yy < H && xx >= 0 && xx < W);
-                    return ok ? (f16)acc[e] : (f16)0.f;
-                };
-#pragma unroll
-                for (int e = 0; e < 2; ++e) bA[e * ROWH] = val(e, e + 8 * h, false);
-#pragma unroll
-                for (int e = 2; e < 8; ++e) bB[e * ROWH] = val(e, h ? e - 2 : e, h != 0);
-                if (h == 0) {
-#pragma unroll
-                    for (int e = 8; e < 12; ++e) bC[(e - 8) * ROWH] = val(e, e - 2, true);
-                }
-            }
-        }
-    };
+        for (int s = 0; s < KS; ++s) xa[2][s] = xa[1][s];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk 0's weights has landed (the pixels were waited for anyway)
+    lds_barrier();                                     // ... and everybody else's
 
-    // ---- depthwise 3x3 of chunk j: this wave's four units = the two halves of patch rows 2 wave, 2 wave + 1
+    // ---- main loop.  Interval j = chunk j's 1x1 (into hidden buffer j & 1) + chunk j-1's depthwise units (out of buffer (j-1) & 1), one barrier
+    // per interval.  The two are independent instruction streams of the same wave and are INTERLEAVED BY HAND: a group's 2 KS MFMAs pair with
+    // the three halo rows of one depthwise unit, 2 KS / 3 MFMAs per row, each followed by its share of the row's 24 v_fma_mix (6 at C = 96): the
+    // vector instructions issue in the shadow of the MFMAs (an MFMA holds the SIMD's issue for 8 of its 32 cycles) instead of after them.
+    // A row's three LDS reads are requested one row ahead.  The fourth unit has no MFMAs beside it; the next chunk's weight fragments are
+    // requested in front of it, into the registers the last MFMA has just read (one weight set: a second one meant spills at C = 96).
+    struct Row { u32x4 m; u32x2 l, r; };
+    constexpr int MPR = 2 * KS / 3;                    // MFMAs per halo row of the paired unit (4 at C = 96, 2 at C = 48)
+    constexpr int FPM = 24 / MPR;                      // v_fma_mix per MFMA
+    static_assert(2 * KS % 3 == 0 && 24 % MPR == 0, "pairing of MFMAs and depthwise rows");
     f16* scr = scr_all + (size_t)wave * (SCR_BYTES / 2);
-    auto units = [&](auto Jc, auto SETc, auto INc) __attribute__((always_inline)) {
-        constexpr int j = decltype(Jc)::value, set = decltype(SETc)::value;
-        constexpr bool inside = decltype(INc)::value;
-        const f16* hp = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
-        const int ch = 32 * j + chl;
+    const int lofs = c * RS + 8 * h;                   // this lane's slot inside a halo row's block of records (halfs)
+#define Q3_PIN() __builtin_amdgcn_sched_barrier(0)
+
+    auto row_request = [&](const f16* hp, int ui, int dy) __attribute__((always_inline)) -> Row {
+        const int ry = 2 * wave + (ui >> 1), b = 2 * (ui & 1) + h;
+        const f16* rec = hp + REC0 + ((ry + dy) * 32 + c) * RS + 8 * b;
+        Row rw;
+        rw.m = *(const u32x4*)rec; rw.l = *(const u32x2*)(rec - 4); rw.r = *(const u32x2*)(rec + 8);
+        return rw;
+    };
+    // FMAs n0 .. n0+cnt-1 of a row's 24 (n = 8 dx + p): element e = p + dx - 1 of the row segment: -1 = l[1] high half, 0..7 = m, 8 = r[0] low half
+    auto row_fma = [&](float (&acc)[8], const Row& rw, const float (&w)[9], int dy, int n0, int cnt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ui = 0; ui < 4; ++ui) {
-            const int ry = 2 * wave + (ui >> 1), b = 2 * (ui & 1) + h;
-            const int oy = y0 + ry;
-            float acc[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p] = biasd[set];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const f16* rec = hp + REC0 + ((ry + dy) * 32 + c) * RS + 8 * b;
-                const u32x4 m = *(const u32x4*)rec;
-                const u32x2 lft = *(const u32x2*)(rec - 4), rgt = *(const u32x2*)(rec + 8);
-                // element e of the row segment (e = -1 .. 8): -1 = lft[1] high half, 0..7 = m, 8 = rgt[0] low half
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float w = wv[set][dy * 3 + dx];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const int e = p + dx - 1;
-                        if (e < 0) fma_mix_hi(acc[p], lft[1], w);
-                        else if (e == 8) fma_mix_lo(acc[p], rgt[0], w);
-                        else if (e & 1) fma_mix_hi(acc[p], m[e >> 1], w);
-                        else fma_mix_lo(acc[p], m[e >> 1], w);
-                    }
-                }
-            }
-            const int ox = x0 + 8 * b;
-            if constexpr (j < NQK) {
-                // q / k: the lane's 8 pixels of channel ch are one element of the pixel-minor tensor.  Rows are padded to WB * 8 pixels and the
-                // padding must read as zero for the Gram: store every block below WB * 8, zeros for x >= W
-                if (inside || (oy < H && ox < WB * 8)) {
-                    u32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float lo = (inside || ox + 2 * k < W) ? acc[2 * k] : 0.f, hi = (inside || ox + 2 * k + 1 < W) ? acc[2 * k + 1] : 0.f;
-                        o[k] = pack2(lo, hi);
-                    }
-                    *(u32x4*)(qk + ((((long)t * H + oy) * WB + (ox >> 3)) * (2 * C) + ch) * 8) = o;
-                }
-            } else {
-                // v (NHWC): transpose the wave's 16 pixels x 32 channels through LDS, then 16-byte pieces of 8 channels of one pixel
-#pragma unroll
-                for (int p = 0; p < 8; ++p) scr[(8 * h + p) * SCR_STRIDE + chl] = (f16)acc[p];
-                // the read below takes what OTHER lanes of this wave wrote: LDS operations of one wave execute in order, the compiler
-                // must not move the read above the writes
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const int p16 = lane >> 2, o8 = lane & 3;
-                const u32x4 o = *(const u32x4*)(scr + p16 * SCR_STRIDE + 8 * o8);
-                const int vx = x0 + 16 * (ui & 1) + p16, vch = 32 * j - 2 * C + 8 * o8;
-                if ((inside || (oy < H && vx < W)) && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
+        for (int n = n0; n < n0 + cnt; ++n) {
+            const int dx = n >> 3, p = n & 7, e = p + dx - 1;
+            const float wt = w[dy * 3 + dx];
+            if (e < 0) fma_mix_hi(acc[p], rw.l[1], wt);
+            else if (e == 8) fma_mix_lo(acc[p], rw.r[0], wt);
+            else if (e & 1) fma_mix_hi(acc[p], rw.m[e >> 1], wt);
+            else fma_mix_lo(acc[p], rw.m[e >> 1], wt);
         }
     };
+    // a finished unit: q,k as one pixel-minor element per lane, v through the per-wave transposition
+    auto unit_store = [&](int j, int ui, const float (&acc)[8], auto INc) __attribute__((always_inline)) {
+        constexpr bool in = decltype(INc)::value;
+        const int ry = 2 * wave + (ui >> 1), b = 2 * (ui & 1) + h;
+        const int oy = y0 + ry, ox = x0 + 8 * b;
+        if (j < NQK) {
+            // rows of the pixel-minor tensor are padded to WB * 8 pixels and the padding must read as zero for the Gram: store every block
+            // below WB * 8, zeros for x >= W
+            if (in || (oy < H && ox < WB * 8)) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = (in || ox + 2 * k < W) ? acc[2 * k] : 0.f, hi = (in || ox + 2 * k + 1 < W) ? acc[2 * k + 1] : 0.f;
+                    o[k] = pack2(lo, hi);
+                }
+                *(u32x4*)(qk + ((((long)t * H + oy) * WB + (ox >> 3)) * (2 * C) + 32 * j + chl) * 8) = o;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) scr[(8 * h + p) * SCR_STRIDE + chl] = (f16)acc[p];
+            // the read below takes what OTHER lanes of this wave wrote: LDS operations of one wave execute in order, the compiler must
+            // not move the read above the writes
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int p16 = lane >> 2, o8 = lane & 3;
+            const u32x4 o = *(const u32x4*)(scr + p16 * SCR_STRIDE + 8 * o8);
+            const int vx = x0 + 16 * (ui & 1) + p16, vch = 32 * j - 2 * C + 8 * o8;
+            if ((in || (oy < H && vx < W)) && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // a finished group of the 1x1 -> hidden buffer (zeros for pixels outside the image: the zero padding of the depthwise conv)
+    auto group_store = [&](f16* hp, int gi, const f32x16& acc, auto INc) __attribute__((always_inline)) {
+        constexpr bool in = decltype(INc)::value;
+        const int g = wave + NW * gi;
+        if (g < NG - 1) {
+            // a halo row's 32 interior pixels: this lane owns pixels 8h .. 8h+7 (registers 0-7) and 16+8h .. 16+8h+7 (8-15) of its channel
+            const int hy = g < TH ? g + 1 : (g == TH ? 0 : PH - 1);
+            u32x4 o1, o2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o1[k] = pack2(acc[2 * k], acc[2 * k + 1]); o2[k] = pack2(acc[8 + 2 * k], acc[8 + 2 * k + 1]); }
+            if constexpr (!in) {
+                const int yy = y0 - 1 + hy;
+                const bool rowok = yy >= 0 && yy < H;
+                const int n1 = rowok ? W - x0 - 8 * h : 0, n2 = rowok ? W - x0 - 16 - 8 * h : 0;      // valid pixels of the two runs
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o1[k] &= (2 * k < n1 ? 0xFFFFu : 0u) | (2 * k + 1 < n1 ? 0xFFFF0000u : 0u);
+                    o2[k] &= (2 * k < n2 ? 0xFFFFu : 0u) | (2 * k + 1 < n2 ? 0xFFFF0000u : 0u);
+                }
+            }
+            f16* rec = hp + REC0 + hy * 32 * RS + lofs;
+            *(u32x4*)rec = o1;
+            *(u32x4*)(rec + 16) = o2;
+        } else if (g == NG - 1) {
+            // the two halo columns.  Group pixel p < 10 = left column (slot -1 of the record) of halo row p, p < 20 = right column (slot 32)
+            // of halo row p - 10; a lane holds p = 8h + e (registers e = 0..7) and 16 + 8h + e (8..15):
+            //   e = 0, 1:  h = 0: left rows 0, 1          h = 1: left rows 8, 9
+            //   e = 2..7:  h = 0: left rows 2..7          h = 1: right rows 0..5
+            //   e = 8..11: h = 0: right rows 6..9         h = 1: nothing (p >= 24)
+            constexpr int ROWH = 32 * RS;                  // halfs per halo row
+            f16* col = hp + REC0 + (lofs - 8 * h);         // record (halo row 0, this lane's channel)
+            f16* bA = col - 1 + (h ? 8 * ROWH : 0);
+            f16* bB = h ? col + 32 - 2 * ROWH : col - 1;
+            f16* bC = col + 32 + 6 * ROWH;
+            auto val = [&](int e, int hy, bool right) __attribute__((always_inline)) -> f16 {
+                const int yy = y0 - 1 + hy, xx = right ? x0 + TW : x0 - 1;
+                const bool ok = in || (yy >= 0 && yy < H && xx >= 0 && xx < W);
+                return ok ? (f16)acc[e] : (f16)0.f;
+            };
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bA[e * ROWH] = val(e, e + 8 * h, false);
+#pragma unroll
+            for (int e = 2; e < 8; ++e) bB[e * ROWH] = val(e, h ? e - 2 : e, h != 0);
+            if (h == 0) {
+#pragma unroll
+                for (int e = 8; e < 12; ++e) bC[(e - 8) * ROWH] = val(e, e - 2, true);
+            }
+        }                                                  // (g == NG: wave 3's discarded group)
+    };
 
-    // ---- main loop: interval j = chunk j's 1x1 (into buffer j & 1) + chunk j-1's depthwise units (out of buffer (j-1) & 1); one barrier per interval.
-    // Weight sets alternate with the chunk parity; chunk j + 1's fragments and depthwise weights are requested at the top of interval j.
-    auto run = [&](auto INc) __attribute__((always_inline)) {
-        auto interval = [&](auto Jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(Jc)::value;         // 0 .. NCH
-            if constexpr (j < NCH) produce(j, IC<0>{}, INc);
-            // chunk j + 1's weight fragments are requested INTO THE SAME REGISTERS, behind the last MFMA that reads them: they arrive under this
-            // interval's depthwise units.  (Requested at the top of the interval into a second set they were 48 more live registers: spills.)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 1 < NCH) load_w(j + 1, IC<0>{});
-            if constexpr (j < NCH) load_dw(j, IC<j & 1>{});                     // (used by the units of the NEXT interval)
-            __builtin_amdgcn_sched_barrier(0);
-            Q3STAMP();
-            if constexpr (j > 0) units(IC<(j > 0 ? j - 1 : 0)>{}, IC<((j > 0 ? j - 1 : 0)) & 1>{}, INc);
-            Q3STAMP();
-            if constexpr (j < NCH) lds_barrier();
-            Q3STAMP();
+    // one interval; PR: it has a 1x1 (chunk j), UN: it has depthwise units (chunk j-1); PAR = (j - 1) & 1 = the depthwise weight set of the units
+    auto interval = [&](int j, auto PRc, auto UNc, auto PARc, auto INc) __attribute__((always_inline)) {
+        constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value;
+        constexpr int par = decltype(PARc)::value;     // (j - 1) & 1: the units' depthwise weight set, the next chunk's weight stage and bias slot
+        constexpr bool in = decltype(INc)::value;
+        f16* hpw = hpb + (size_t)(j & 1) * (HPT_BYTES / 2);
+        const f16* hpr = hpb + (size_t)((j - 1) & 1) * (HPT_BYTES / 2);
+        const char* wcur = wst + (size_t)(j & 1) * WST + lane * 16;
+        if constexpr (pr) {
+            load_dw(j, IC<par ^ 1>{});                                          // chunk j's depthwise weights: used by the NEXT interval's units
+            if (j + 1 < NCH) { stage_w(j + 1); load_b1(j + 1, IC<par>{}); }     // chunk j + 1's weights -> stage (j + 1) & 1 (read last in interval j - 1)
+        }
+        // FRAGMENT-MAJOR order: a weight fragment is read from LDS once and used by the three groups' MFMAs (three accumulators live); the
+        // interval's 3 NF MFMAs are paired with the 288 v_fma_mix of the four depthwise units (12 halo rows of 24), FPM per MFMA, in order.
+        constexpr int NM = 3 * NF, FPM2 = 288 / NM;
+        static_assert(288 % NM == 0, "FMAs per MFMA");
+        f32x16 acc[3];
+        float ua[8];
+        Row cur{}, nxt{};
+        half8 bw{}, bwn{};
+        if constexpr (pr) {
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[gi][e] = bias1[par ^ 1];
+            bw = *(const half8*)wcur;
+        }
+        if constexpr (un) cur = row_request(hpr, 0, 0);
+        auto fma_slot = [&](auto Qc) __attribute__((always_inline)) {            // FMAs Q * FPM2 .. of the interval's 288
+            constexpr int q = decltype(Qc)::value;
+#pragma unroll
+            for (int n = q * FPM2; n < (q + 1) * FPM2; ++n) {
+                const int rowi = n / 24, k = n - rowi * 24, ui = rowi / 3, dy = rowi - ui * 3;
+                if (k == 0) {
+                    if (rowi > 0) cur = nxt;
+                    if (rowi + 1 < 12) nxt = row_request(hpr, (rowi + 1) / 3, (rowi + 1) % 3);                    // one row ahead
+                    if (dy == 0) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) ua[p] = biasd[par];
+                    }
+                }
+                row_fma(ua, cur, wv[par], dy, k, 1);
+                if (k == 23 && dy == 2) unit_store(j - 1, ui, ua, INc);
+            }
         };
-        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) { (interval(IC<J>{}), ...); }(std::make_integer_sequence<int, NCH + 1>{});
+        [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int q = Q, ms = q / 3, gi = q % 3, sk = ms >> 1;       // fragment ms: k-step sk, plane ms & 1 (hi, then lo: the order of the other generations)
+                if constexpr (pr) {
+                    if constexpr (gi == 0 && ms + 1 < NF) { constexpr int msn = ms + 1, fn = (msn & 1) * KS + (msn >> 1); bwn = *(const half8*)(wcur + fn * 1024); }
+                    acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][sk], bw, acc[gi], 0, 0, 0);
+                    if constexpr (gi == 2) bw = bwn;
+                }
+                if constexpr (un) fma_slot(IC<q>{});
+                Q3_PIN();
+            }(), ...);
+        }(std::make_integer_sequence<int, NM>{});
+        if constexpr (pr) {
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi) group_store(hpw, gi, acc[gi], INc);
+        }
+        Q3STAMP();
+        if constexpr (pr) {
+            // the DMA pieces of chunk j + 1 are older than this interval's stores on the wave's vector-memory counter: inside the image the four
+            // unit stores are unconditional, so vmcnt(4) retires the pieces and leaves the stores in flight
+            if (in && un) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        Q3STAMP();
+    };
+    auto run = [&](auto INc) __attribute__((always_inline)) {
+        using Tt = std::true_type; using Ff = std::false_type;
+        interval(0, Tt{}, Ff{}, IC<1>{}, INc);             // chunk 0's 1x1 alone (its depthwise weights go to set 0, its bias came in slot 0)
+        static_assert((NCH - 1) % 2 == 0, "steady intervals come in (odd, even) pairs");
+#pragma unroll 1
+        for (int j = 1; j < NCH; j += 2) {
+            interval(j, Tt{}, Tt{}, IC<0>{}, INc);         // units of chunk j - 1 (even): weight set 0
+            interval(j + 1, Tt{}, Tt{}, IC<1>{}, INc);
+        }
+        interval(NCH, Ff{}, Tt{}, IC<(NCH - 1) & 1>{}, INc);
     };
     if (inside) run(std::true_type{});
     else run(std::false_type{});
+#undef Q3_PIN
 }
 
 #ifdef IRA_KERNEL_DBG
@@ -346,8 +418,8 @@ static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, co
                                f16* v, int T, int H, int W) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, Q3_LDS, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), Q3_LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, Q3_MAIN + 2 * (2 * (C / 16)) * 1024, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), Q3_MAIN + 2 * (2 * (C / 16)) * 1024, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
     return hipGetLastError();
 }
 

@@ -30,8 +30,8 @@ torch.cuda.synchronize(); print('qkv_fused gen %d C=%d T=%d dbg=%s: %.3f ms' % (
 if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 3:
     buf = (C.c_ulonglong * 64)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv3_stamps(buf) == 0
     st = [int(buf[i] - buf[0]) for i in range(64)]
-    print('wave 0 of workgroup 1777: start, pixels + weights requested, group 0 normalised, all normalised, then per interval (1x1 done, units done, barrier passed):')
-    print('   ', st[:4], [tuple(st[4 + 3 * k: 7 + 3 * k]) for k in range(10)])
+    print('wave 0 of workgroup 1777: start, pixels + weights requested, group 0 normalised, all normalised, then per interval (work done, barrier passed):')
+    print('   ', st[:4], [tuple(st[4 + 2 * k: 6 + 2 * k]) for k in range(10)])
 if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 2:
     # make -C image-restoration-agent_amd/csrc dbg; IRA_HIP_LIB=.../libira_hip_dbg.so: s_memtime stamps of workgroup 17 (P wave 0, C wave 4), first patches
     buf = (C.c_ulonglong * 128)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv2_stamps(buf) == 0
