@@ -50,16 +50,13 @@ hipError_t launch_attn_mix(hipStream_t st, const float* part, const float* wo, c
 bool qkv_fused_supported(int C);
 hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq,
                             const float* dww, const float* dwb, void* qk, void* v, int T, int H, int W);
-// Second generation (ira_qkv2.hip): persistent workgroups, halo rows of the next patch requested under the current patch's main loop,
-// transposed 1x1 so that the depthwise conv's lanes own whole pixel-minor q,k elements.  Same arguments, layouts and bits.
-// launch_qkv_front picks the generation: 2 unless IRA_QKV_GEN=1 (A/B on the same box; read once per process).
+// Third generation (ira_qkv3.hip): 4-wave workgroups, two per CU; pixel-stationary TRANSPOSED 1x1 (a depthwise lane owns whole pixel-minor
+// q,k elements); weights staged once per workgroup in LDS by DMA; MFMAs and depthwise FMAs interleaved.  Same arguments, layouts and
+// rounding points as generation 1.  launch_qkv_front picks the generation: 3 unless IRA_QKV_GEN=1 (read once per process).
 hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                             const float* dwb, void* qk, void* v, int T, int H, int W);
 bool qkv3_supported(int C);
 hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
-                       const float* dwb, void* qk, void* v, int T, int H, int W);
-bool qkv2_supported(int C);
-hipError_t launch_qkv2(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                        const float* dwb, void* qk, void* v, int T, int H, int W);
 
 // Fused GDFN (ira_ffn_fused.hip): x_out = x + ffn(LN(x)); x_out must not alias x.  Supported for C in {48, 96}.

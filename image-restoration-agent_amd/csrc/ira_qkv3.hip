@@ -1,6 +1,6 @@
 // Fused attention front end, third generation (restormer_arch.py:114 after :146's norm1):
 //     qkv = dwconv3x3( conv1x1( LN(x) ) )            q,k -> fp16 pixel-minor [T][H][ceil(W/8)][2C][8], v -> fp16 NHWC
-// Same contract, layouts and rounding points as ira_qkv_fused.hip (generation 1) and ira_qkv2.hip (generation 2).
+// Same contract, layouts and rounding points as ira_qkv_fused.hip (generation 1).
 //
 // What the first two measured: a CU's share of HBM bandwidth is ~10 bytes per cycle, a patch moves 277 KB (28k cycles), and
 // both generations take 51-64k cycles per patch because ONE workgroup per CU walks through its phases in series: while it waits for its
@@ -74,7 +74,9 @@ __device__ unsigned long long g_qkv3_stamps[64];        // s_memtime of wave 0 o
 #define Q3STAMP() do {} while (0)
 #endif
 
-template <int C, int LN, bool BIN, bool CB>
+// DBG (measurement variants, wrong results; instantiated and selectable - IRA_QKV3_DBG - only in the `make dbg` library): 1 = no global
+// stores, 2 = no pixel loads, 4 = no MFMAs, 8 = no depthwise FMAs, 16 = no LDS traffic of the hidden tile (bits may be combined)
+template <int C, int LN, bool BIN, bool CB, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x, const f16* __restrict__ Wq, const float* __restrict__ bq,
                                                      const float* __restrict__ dww, const float* __restrict__ dwb, f16* __restrict__ qk,
                                                      f16* __restrict__ vout, int T, int H, int W) {
@@ -134,30 +136,72 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
         biasd[set] = (CB && ch < NQ) ? dwb[chc] : 0.f;
     };
 
-    // ---- prologue: this wave's pixels -> LayerNorm -> A fragments (A row c of a group holds pixel rowperm(c))
+    // ---- prologue: this wave's pixels -> LayerNorm -> A fragments (A row c of a group holds pixel rowperm(c)).
+    // A group's 32 pixels (C floats each) are fetched as WHOLE 128-byte lines - instruction i of a group: lanes 8k .. 8k+7 = line i / 4 of pixel
+    // 8 (i % 4) + k, 8 lines per instruction - parked in this wave's 12.5 KB of the (still idle) hidden-buffer region with a pixel stride of
+    // C + 4 floats, and read back in fragment shape.  Fetched in fragment shape straight from memory (16 bytes per lane at the pixel stride:
+    // 32 lines per instruction, each touched by four instructions) the texture path needed 8.9k cycles just to take the 24 requests.
     half8 xa[3][KS];
     {
-        f32x4 xlo[3][KS], xhi[3][KS];
-        auto request = [&](auto GIc) __attribute__((always_inline)) {
-            constexpr int gi = decltype(GIc)::value;
-            int hy, hx;
-            group_px(wave + NW * gi, chl, hy, hx);
-            int yy = y0 - 1 + (hy < 0 ? 0 : hy), xx = x0 - 1 + hx;
-            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);                      // pixels outside the image: any finite values (their hidden values are zeroed)
-            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            const float* src = xt + ((long)yy * W + xx) * C + 8 * h;
+        constexpr int XS = C + 4;                      // staging stride in floats: conflict-free 16-byte reads at pixel granularity
+        constexpr int PP = C / 4;                      // 16-byte pieces per pixel
+        constexpr int NSG = (PP + 7) / 8;              // 128-byte segments per pixel (C = 48: the second one is half used)
+        constexpr int NLD = 4 * NSG;                   // requests per group
+        static_assert((size_t)NW * 32 * XS * 4 <= 2 * HPT_BYTES, "pixel staging must fit the hidden-buffer region");
+        float* stg = (float*)smem + (size_t)wave * 32 * XS;
+        f32x4 raw[2][NLD];
+        // lane part of a request's address (floats): pixel lane / 8 of the instruction's pixel octet, piece lane % 8 of the segment (the last
+        // segment of a C = 48 pixel is half used: its upper lanes repeat piece PP - 1 and are not written to the staging area)
+        const int voff = (lane >> 3) * C + 4 * (lane & 7);
+        const int pcl = 8 * (NSG - 1) + (lane & 7);
+        const int voff_last = (lane >> 3) * C + 4 * (pcl < PP ? pcl : PP - 1);
+        auto request = [&](int gi, auto SETc) __attribute__((always_inline)) {
+            constexpr int set = decltype(SETc)::value;
+            const int g = wave + NW * gi;
+            if (inside && g < NG - 1) {
+                // a halo row's 32 interior pixels of a patch inside the image: a wave-uniform base + the lane part, no clamping
+                const int hy = g < TH ? g + 1 : (g == TH ? 0 : PH - 1);
+                const float* gb = xt + ((long)(y0 - 1 + hy) * W + x0) * C;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) { xlo[gi][s] = *(const f32x4*)(src + 16 * s); xhi[gi][s] = *(const f32x4*)(src + 16 * s + 4); }
+                for (int i = 0; i < NLD; ++i) raw[set][i] = (DBG & 2) ? f32x4{0.1f * (lane & 7), 0.3f, -0.2f, 0.05f * i}
+                                                                      : *(const f32x4*)(gb + 8 * (i % 4) * C + ((i / 4 == NSG - 1) ? voff_last : 32 * (i / 4) + voff));
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int p = 8 * (i % 4) + (lane >> 3);
+                int hy, hx;
+                group_px(g, p, hy, hx);
+                int yy = y0 - 1 + (hy < 0 ? 0 : hy), xx = x0 - 1 + hx;
+                yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);                  // pixels outside the image: any finite values (their hidden values are zeroed)
+                xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                const int pc = 8 * (i / 4) + (lane & 7);
+                if constexpr (DBG & 2) { raw[set][i] = f32x4{0.1f * (lane & 7), 0.3f, -0.2f, 0.05f * i}; (void)yy; (void)xx; (void)pc; }
+                else raw[set][i] = *(const f32x4*)(xt + ((long)yy * W + xx) * C + 4 * (pc < PP ? pc : PP - 1));
+            }
         };
-        auto normalise = [&](auto GIc) __attribute__((always_inline)) {
-            constexpr int gi = decltype(GIc)::value;
+        auto normalise = [&](int gi, auto SETc) __attribute__((always_inline)) {
+            constexpr int set = decltype(SETc)::value;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int pc = 8 * (i / 4) + (lane & 7);
+                if (8 * (i / 4) + 8 <= PP || pc < PP) *(f32x4*)(stg + (8 * (i % 4) + (lane >> 3)) * XS + 4 * pc) = raw[set][i];
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();           // (the reads below take what other lanes of this wave wrote: LDS operations of a wave execute in order)
+            const float* src = stg + chl * XS + 8 * h;
+            f32x4 xlo[KS], xhi[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { xlo[s] = *(const f32x4*)(src + 16 * s); xhi[s] = *(const f32x4*)(src + 16 * s + 4); }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
             float sum = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sum += xlo[gi][s][j];
+                for (int j = 0; j < 4; ++j) sum += xlo[s][j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sum += xhi[gi][s][j];
+                for (int j = 0; j < 4; ++j) sum += xhi[s][j];
             }
             sum += __shfl_xor(sum, 32);
             const float mu = sum * (1.0f / C);
@@ -165,9 +209,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = xlo[gi][s][j] - mu; sq += d * d; }
+                for (int j = 0; j < 4; ++j) { const float d = xlo[s][j] - mu; sq += d * d; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = xhi[gi][s][j] - mu; sq += d * d; }
+                for (int j = 0; j < 4; ++j) { const float d = xhi[s][j] - mu; sq += d * d; }
             }
             sq += __shfl_xor(sq, 32);
             const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
@@ -176,21 +220,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
             for (int s = 0; s < KS; ++s) {
                 half8 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { o[j] = (f16)((xlo[gi][s][j] - sub) * rstd); o[4 + j] = (f16)((xhi[gi][s][j] - sub) * rstd); }
+                for (int j = 0; j < 4; ++j) { o[j] = (f16)((xlo[s][j] - sub) * rstd); o[4 + j] = (f16)((xhi[s][j] - sub) * rstd); }
                 xa[gi][s] = o;
             }
         };
         stage_w(0);
         load_b1(0, IC<0>{});
-        request(IC<0>{}); request(IC<1>{});
+        request(0, IC<0>{}); request(1, IC<1>{});
         Q3STAMP();
-        normalise(IC<0>{});
+        normalise(0, IC<0>{});
         Q3STAMP();
-        __builtin_amdgcn_sched_barrier(0);             // (the third group's 48 registers are the first group's: at most two groups of raw pixels are live)
-        if (ngroups > 2) request(IC<2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        normalise(IC<1>{});
-        if (ngroups > 2) normalise(IC<2>{});
+        if (ngroups > 2) request(2, IC<0>{});
+        normalise(1, IC<1>{});
+        if (ngroups > 2) normalise(2, IC<0>{});
         Q3STAMP();
     }
 
@@ -210,9 +252,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
     // A row's three LDS reads are requested one row ahead.  The fourth unit has no MFMAs beside it; the next chunk's weight fragments are
     // requested in front of it, into the registers the last MFMA has just read (one weight set: a second one meant spills at C = 96).
     struct Row { u32x4 m; u32x2 l, r; };
-    constexpr int MPR = 2 * KS / 3;                    // MFMAs per halo row of the paired unit (4 at C = 96, 2 at C = 48)
-    constexpr int FPM = 24 / MPR;                      // v_fma_mix per MFMA
-    static_assert(2 * KS % 3 == 0 && 24 % MPR == 0, "pairing of MFMAs and depthwise rows");
     f16* scr = scr_all + (size_t)wave * (SCR_BYTES / 2);
     const int lofs = c * RS + 8 * h;                   // this lane's slot inside a halo row's block of records (halfs)
 #define Q3_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -251,7 +290,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
                     const float lo = (in || ox + 2 * k < W) ? acc[2 * k] : 0.f, hi = (in || ox + 2 * k + 1 < W) ? acc[2 * k + 1] : 0.f;
                     o[k] = pack2(lo, hi);
                 }
-                *(u32x4*)(qk + ((((long)t * H + oy) * WB + (ox >> 3)) * (2 * C) + 32 * j + chl) * 8) = o;
+                if constexpr (DBG & 1) asm volatile("" :: "v"(o));
+                else *(u32x4*)(qk + ((((long)t * H + oy) * WB + (ox >> 3)) * (2 * C) + 32 * j + chl) * 8) = o;
             }
         } else {
 #pragma unroll
@@ -263,7 +303,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
             const int p16 = lane >> 2, o8 = lane & 3;
             const u32x4 o = *(const u32x4*)(scr + p16 * SCR_STRIDE + 8 * o8);
             const int vx = x0 + 16 * (ui & 1) + p16, vch = 32 * j - 2 * C + 8 * o8;
-            if ((in || (oy < H && vx < W)) && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
+            if constexpr (DBG & 1) asm volatile("" :: "v"(o));
+            else if ((in || (oy < H && vx < W)) && vch < C) *(u32x4*)(vout + (((long)t * H + oy) * W + vx) * C + vch) = o;
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -359,7 +400,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
                         for (int p = 0; p < 8; ++p) ua[p] = biasd[par];
                     }
                 }
-                row_fma(ua, cur, wv[par], dy, k, 1);
+                if constexpr (DBG & 8) asm volatile("" :: "v"(cur.m), "v"(cur.l), "v"(cur.r));
+                else row_fma(ua, cur, wv[par], dy, k, 1);
                 if (k == 23 && dy == 2) unit_store(j - 1, ui, ua, INc);
             }
         };
@@ -368,7 +410,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
                 constexpr int q = Q, ms = q / 3, gi = q % 3, sk = ms >> 1;       // fragment ms: k-step sk, plane ms & 1 (hi, then lo: the order of the other generations)
                 if constexpr (pr) {
                     if constexpr (gi == 0 && ms + 1 < NF) { constexpr int msn = ms + 1, fn = (msn & 1) * KS + (msn >> 1); bwn = *(const half8*)(wcur + fn * 1024); }
-                    acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][sk], bw, acc[gi], 0, 0, 0);
+                    if constexpr (DBG & 4) asm volatile("" :: "v"(xa[gi][sk]), "v"(bw));
+                    else acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][sk], bw, acc[gi], 0, 0, 0);
                     if constexpr (gi == 2) bw = bwn;
                 }
                 if constexpr (un) fma_slot(IC<q>{});
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
         if constexpr (pr) {
             // the DMA pieces of chunk j + 1 are older than this interval's stores on the wave's vector-memory counter: inside the image the four
             // unit stores are unconditional, so vmcnt(4) retires the pieces and leaves the stores in flight
-            if (in && un) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (in && un && !(DBG & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
         }
@@ -417,9 +460,24 @@ template <int C, int LN, bool BIN, bool CB>
 static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww, const float* dwb, f16* qk,
                                f16* v, int T, int H, int W) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    constexpr size_t LDS = Q3_MAIN + 2 * (2 * (C / 16)) * 1024;
+#ifdef IRA_KERNEL_DBG
+    if constexpr (C == 96 && LN == 1 && !BIN && !CB) {
+        static const int dbg = getenv("IRA_QKV3_DBG") ? atoi(getenv("IRA_QKV3_DBG")) : 0;
+#define IRA_Q3_DBG(D_)                                                                                                                   \
+    if (dbg == D_) {                                                                                                                      \
+        static std::atomic<uint64_t> ad{0};                                                                                               \
+        if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB, D_>, LDS, ad); e != hipSuccess) return e;               \
+        hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB, D_>), dim3((unsigned)nblk), dim3(64 * NW), LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W); \
+        return hipGetLastError();                                                                                                         \
+    }
+        IRA_Q3_DBG(1) IRA_Q3_DBG(2) IRA_Q3_DBG(3) IRA_Q3_DBG(4) IRA_Q3_DBG(8) IRA_Q3_DBG(12) IRA_Q3_DBG(15)
+#undef IRA_Q3_DBG
+    }
+#endif
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, Q3_MAIN + 2 * (2 * (C / 16)) * 1024, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), Q3_MAIN + 2 * (2 * (C / 16)) * 1024, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, LDS, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
     return hipGetLastError();
 }
 
@@ -442,6 +500,14 @@ hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const
     if ((ln_mode != 1 && ln_mode != 2) || !qkv3_supported(C)) return hipErrorInvalidValue;
     if (C == 48) return qkv3_launch<48>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
     return qkv3_launch<96>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+}
+
+// The network schedule's entry: generation 3 unless IRA_QKV_GEN=1 (A/B on the same box; read once per process).
+hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
+                            const float* dwb, void* qk, void* v, int T, int H, int W) {
+    static const int gen = getenv("IRA_QKV_GEN") ? atoi(getenv("IRA_QKV_GEN")) : 3;
+    if (gen == 1) return launch_qkv_fused(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
+    return launch_qkv3(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
 }
 
 }  // namespace ira

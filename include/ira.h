@@ -412,10 +412,11 @@ int ira_get_weight_planes(ira_model_t* m, int* planes);
  * [9][3C], dwb [3C] or NULL; outputs as ira_op_dwconv_qkv: q,k pixel-minor (T,H,ceil(W/8),2C,8), v NHWC (T,H,W,C). */
 int ira_op_qkv_fused(ira_model_t* m, const float* x_dev, int ln_mode, int C, const void* Wq_dev, const float* bq_dev,
                      const float* dww_dev, const float* dwb_dev, void* qk_dev, void* v_dev, int T, int H, int W);
-/* The same op on a named kernel generation (A/B and bit-identity tests): 1 = csrc/ira_qkv_fused.hip (one workgroup per patch, producer /
- * consumer waves), 2 = csrc/ira_qkv2.hip (persistent workgroups, the next patch's halo rows requested under the current patch's main loop,
- * transposed 1x1 so that a depthwise lane owns whole pixel-minor elements).  ira_op_qkv_fused and the network schedule run generation 2
- * unless the environment variable IRA_QKV_GEN is 1. */
+/* The same op on a named kernel generation (A/B and equivalence tests): 1 = csrc/ira_qkv_fused.hip (one 8-wave workgroup per patch and
+ * CU, producer / consumer waves), 3 = csrc/ira_qkv3.hip (4-wave workgroups, two per CU, pixel-stationary transposed 1x1 so that a depthwise
+ * lane owns whole pixel-minor elements, weights staged once per workgroup in LDS, MFMAs and depthwise FMAs interleaved).  (Generation 2, a
+ * persistent one-workgroup-per-CU kernel that requested the next patch's halo rows under the main loop, was no faster than generation 1 and
+ * is not in the library: DESIGN.md 5j.)  ira_op_qkv_fused and the network schedule run generation 3 unless IRA_QKV_GEN=1. */
 int ira_op_qkv_fused_gen(ira_model_t* m, int gen, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                          const float* dwb, void* qk, void* v, int T, int H, int W);
 

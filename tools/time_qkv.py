@@ -20,23 +20,13 @@ d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in arrs.items(
 x = torch.randn(T, H, W, Cc, generator=g).cuda()
 qk = torch.empty(T, H, W // 8, 2 * Cc, 8, dtype=torch.float16, device='cuda'); v = torch.empty(T, H, W, Cc, dtype=torch.float16, device='cuda')
 p = lambda t: C.c_void_p(t.data_ptr())
-if os.environ.get('QDBG'):
-    assert C.CDLL(os.environ['IRA_HIP_LIB']).ira_debug_qkv2_flags(int(os.environ['QDBG'])) == 0
 def run():
     rc = be._lib.ira_op_qkv_fused_gen(be.handle, GEN, p(x), 1, Cc, p(d['b.qkv_w']), None, p(d['b.dw1_w']), None, p(qk), p(v), T, H, W); assert rc == 0
 run(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): run()
-torch.cuda.synchronize(); print('qkv_fused gen %d C=%d T=%d dbg=%s: %.3f ms' % (GEN, Cc, T, os.environ.get('QDBG', '0'), (time.perf_counter() - t0) * 100))
+torch.cuda.synchronize(); print('qkv_fused gen %d C=%d T=%d dbg=%s: %.3f ms' % (GEN, Cc, T, os.environ.get('IRA_QKV3_DBG', os.environ.get('QDBG', '0')), (time.perf_counter() - t0) * 100))
 if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 3:
     buf = (C.c_ulonglong * 64)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv3_stamps(buf) == 0
     st = [int(buf[i] - buf[0]) for i in range(64)]
     print('wave 0 of workgroup 1777: start, pixels + weights requested, group 0 normalised, all normalised, then per interval (work done, barrier passed):')
     print('   ', st[:4], [tuple(st[4 + 2 * k: 6 + 2 * k]) for k in range(10)])
-if os.environ.get('IRA_HIP_LIB', '').endswith('dbg.so') and GEN == 2:
-    # make -C image-restoration-agent_amd/csrc dbg; IRA_HIP_LIB=.../libira_hip_dbg.so: s_memtime stamps of workgroup 17 (P wave 0, C wave 4), first patches
-    buf = (C.c_ulonglong * 128)(); lib = C.CDLL(os.environ['IRA_HIP_LIB']); assert lib.ira_debug_qkv2_stamps(buf) == 0
-    prod = [buf[i] for i in range(64)]; cons = [buf[64 + i] for i in range(64)]; t0 = min(prod[0], cons[0])
-    print('P wave 0 (before B0, after B0, after B1, LN done, after B2, then produce done / barrier passed per chunk):')
-    print('   ', [int(v - t0) for v in prod])
-    print('C wave 4 (before B0, after B0, staging written, after B1, prefetch issued, chunk 0 ready, then units done / barrier passed per chunk):')
-    print('   ', [int(v - t0) for v in cons])
