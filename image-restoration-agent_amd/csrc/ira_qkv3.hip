@@ -65,6 +65,14 @@ IRA_DEV void group_px(int g, int p, int& hy, int& hx) {
 
 template <int N> using IC = std::integral_constant<int, N>;
 
+// acc = (float)half(lo / hi 16 bits of `packed`) * w: the first tap of a depthwise sum without a bias (no accumulator to clear beforehand)
+IRA_DEV void mul_mix_lo(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "v"(w));
+}
+IRA_DEV void mul_mix_hi(float& acc, unsigned packed, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "v"(w));
+}
+
 }  // namespace
 
 #ifdef IRA_KERNEL_DBG
@@ -269,7 +277,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
         for (int n = n0; n < n0 + cnt; ++n) {
             const int dx = n >> 3, p = n & 7, e = p + dx - 1;
             const float wt = w[dy * 3 + dx];
-            if (e < 0) fma_mix_hi(acc[p], rw.l[1], wt);
+            if (!CB && dy == 0 && dx == 0) {                                   // first tap, no bias: a product (e = p - 1: never 8)
+                if (e < 0) mul_mix_hi(acc[p], rw.l[1], wt);
+                else if (e & 1) mul_mix_hi(acc[p], rw.m[e >> 1], wt);
+                else mul_mix_lo(acc[p], rw.m[e >> 1], wt);
+            }
+            else if (e < 0) fma_mix_hi(acc[p], rw.l[1], wt);
             else if (e == 8) fma_mix_lo(acc[p], rw.r[0], wt);
             else if (e & 1) fma_mix_hi(acc[p], rw.m[e >> 1], wt);
             else fma_mix_lo(acc[p], rw.m[e >> 1], wt);
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
                 if (k == 0) {
                     if (rowi > 0) cur = nxt;
                     if (rowi + 1 < 12) nxt = row_request(hpr, (rowi + 1) / 3, (rowi + 1) % 3);                    // one row ahead
-                    if (dy == 0) {
+                    if (CB && dy == 0) {
 #pragma unroll
                         for (int p = 0; p < 8; ++p) ua[p] = biasd[par];
                     }
