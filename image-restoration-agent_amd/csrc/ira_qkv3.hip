@@ -268,7 +268,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
         const int ry = 2 * wave + (ui >> 1), b = 2 * (ui & 1) + h;
         const f16* rec = hp + REC0 + ((ry + dy) * 32 + c) * RS + 8 * b;
         Row rw;
-        rw.m = *(const u32x4*)rec; rw.l = *(const u32x2*)(rec - 4); rw.r = *(const u32x2*)(rec + 8);
+        // (records are 80 bytes apart and start 16 bytes into the buffer: rec is 16-byte aligned, its neighbours' words 8-byte aligned; told
+        // explicitly, because with 4-byte alignment the compiler reads them as ds_read2_b32, twice the LDS cycles of a ds_read_b64)
+        rw.m = *(const u32x4*)__builtin_assume_aligned(rec, 16);
+        rw.l = *(const u32x2*)__builtin_assume_aligned(rec - 4, 8);
+        rw.r = *(const u32x2*)__builtin_assume_aligned(rec + 8, 8);
         return rw;
     };
     // FMAs n0 .. n0+cnt-1 of a row's 24 (n = 8 dx + p): element e = p + dx - 1 of the row segment: -1 = l[1] high half, 0..7 = m, 8 = r[0] low half
