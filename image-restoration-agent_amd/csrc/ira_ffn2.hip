@@ -334,13 +334,26 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         const int blk = ((r < 16) ? 0 : NBH) + (c >> 1);
         return Win + ((long)blk * KS * 64 + 16 * (c & 1) + (r & 15) + 32 * h) * 8;
     };
-    // weight fragments are requested a whole interval ahead into the other register set (all CUs fetch their next chunk at about the
-    // same moment: the L2 answers such a burst in ~1k cycles, more than the tail of an interval hides)
-    half8 fwh[2][KS], fwl[2][KS];
-    auto load_win = [&](int c, int set) {
+    // r3: the chunk's 2 KS W_in fragments (hi plane, then lo plane; 1 KB each) travel L2 -> LDS by LDS-DMA ONCE per workgroup, one interval
+    // ahead (each P wave moves its share; per-lane source addresses: the row gather above), into stage (chunk & 1); the P waves read them from
+    // there, ONE ds_read_b128 per fragment, and use each for the MFMAs of their three pixel groups (fragment-major order, three accumulators;
+    // a group still sees its products in the old order, so the numbers do not move).  The B operands - the LayerNorm-ed pixels of a P wave's
+    // three groups - stay in 72 registers for the whole patch.  Before (r2): weights in two register sets of 48 per P wave (four private copies
+    // from L2 per chunk) and one ds_read_b128 of a pixel fragment per MFMA pair.  Stage 0 lies behind the Phi table, stage 1 at the start of
+    // the xn region (dead once the P waves hold their fragments).
+    constexpr int NF = 2 * KS;
+    constexpr unsigned WST0 = (unsigned)(XN_BYTES + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES);       // byte offset of stage 0 (stage 1: offset 0)
+    auto stage_win = [&](int c) {                      // P waves only
         const f16* p = win_ptr(c);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { fwh[set][s] = *(const half8*)(p + s * 512); fwl[set][s] = *(const half8*)(p + win_lo + s * 512); }
+        for (int i = 0; i < (NF + 3) / 4; ++i) {
+            const int f = wave + 4 * i;
+            if (f < NF) {
+                const int plane = f >= KS ? 1 : 0, sk = f - plane * KS;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (plane ? win_lo : 0) + sk * 512),
+                                                 (__attribute__((address_space(3))) void*)(smem + ((c & 1) ? 0u : WST0) + f * 1024), 16, 0, 0);
+            }
+        }
     };
     // W_out fragments of chunk c (C waves)
     const int KTO = NCH;
@@ -376,7 +389,6 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     f32x16 uw[2];                          // the slot's weights: [0..7] first half tap, [8..15] second half tap (SGPRs)
     u32x4 uva[2], uvb[2];                  // hp values of the two half taps (8 fp16 each)
     float a1[8], a2[8];
-    half8 bq[2][KPS];                      // P: B fragments of this slot's / the next slot's MFMAs (from the xn region of LDS)
     // LDS byte address of this lane's pixel / octet in hp buffer 0 (all of this kernel's LDS is dynamic: smem starts at LDS offset 0)
     const unsigned hb_lane = (unsigned)XN_BYTES + (unsigned)((((2 * urp + h) * PW + r) * HPS + 8 * uoc) * 2);
     auto unit_request = [&](unsigned hbase, const float* wunit, auto TC, int slot) {       // operands of slot t (half taps 2t, 2t+1)
@@ -453,14 +465,19 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // The (produce, unit) / (unit, consume) activity of an interval is a compile-time property of its body: the first and last
     // intervals are peeled so that the steady-state body carries no branches.
     if (!isC) {
+        stage_win(0);                              // chunk 0's weights -> stage 0 (they land under the prologue; __syncthreads below waits vmcnt(0))
         {
             f32x16 accT[NBC];                      // P: x1 of one group of border pixels, only to LayerNorm it
             prologue(std::false_type{}, accT, accT);
         }
-        load_win(0, 0);
         STAMP();
         __syncthreads();    // (3) done: xn fragments complete; M no longer read: its LDS region becomes the hp / g buffers
         STAMP();
+        half8 xb[3][KS];                           // the B fragments of this wave's pixel groups wave, wave + 4, wave + 8 (wave 3: the third is discarded)
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi)
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) xb[gi][s2] = xnl[((wave + 4 * gi) * KS + s2) * 64 + lane];
 #pragma unroll
         for (int gi = 0; gi < 3; ++gi) {                 // zero padding: this lane's slots of its out-of-image halo pixels, both hp buffers, once
             if (pq[gi] >= 0 && !pin[gi]) {
@@ -473,7 +490,6 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 }
             }
         }
-        f32x16 accp[1];
         auto write_out = [&](const f32x16& acc, f16* hp, int gi) {
             if (DBG == 7 || DBG == 12 || DBG == 13 || DBG == 14 || DBG == 15 || DBG == 16) { asm volatile("" :: "v"(acc)); return; }
             const int q = pq[gi];
@@ -491,24 +507,27 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 *(u32x4*)(hp + (long)q * HPS + 16 + 8 * h) = o2;
             }
         };
+        lds_barrier();      // every P wave holds its fragments: the start of the xn region becomes weight stage 1
+        f32x16 accp[3];
+        constexpr int NMS = 2 * KPS;               // MFMAs per slot (4 at C = 96, 2 at C = 48)
         auto interval = [&](auto PRc, auto UNc, auto PARc, int i) {
             constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value && DBG != 2 && DBG != 12 && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16;
-            constexpr int par = decltype(PARc)::value;                 // i & 1: the weight register set of this interval
-            if (pr && i + 1 < NCH && (DBG != 16 || i == 0)) load_win(i + 1, par ^ 1);
+            if (pr && i + 1 < NCH) stage_win(i + 1);                   // chunk i + 1 -> stage (i + 1) & 1, last read in interval i - 1
             f16* hp = hpbuf + (size_t)(i & 1) * PHW * HPS;
+            const char* wcur = smem + ((i & 1) ? 0u : WST0) + lane * 16;
             const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;       // the unit reads chunk i-1's buffer
             const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
             if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
+            // MFMA q of the interval (q = 0 .. 3 NF - 1): fragment ms = q / 3 = (k-step ms >> 1, plane ms & 1: hi, then lo), group q % 3.
+            // fr[ms] is requested one slot before the slot of its first MFMA.
+            half8 fr[NF];
+            auto frag_ptr = [&](int ms) { return (const half8*)(wcur + ((ms & 1) * KS + (ms >> 1)) * 1024); };
             if (pr) {
 #pragma unroll
-                for (int k = 0; k < KPS; ++k) bq[0][k] = xnl[(wave * KS + k) * 64 + lane];
+                for (int ms = 0; ms <= (NMS - 1) / 3; ++ms) fr[ms] = *frag_ptr(ms);
             }
             auto slot = [&](auto TC) {
-                constexpr int t = decltype(TC)::value, gi = t / 3, sl = t & 1;
-                // wave 3 has two pixel groups only; it runs a third, discarded one (group 11 = whatever follows the xn fragments in LDS;
-                // pq = -1 skips its write-out) rather than branch around it: SIMD 3 then carries the same 48 MFMAs per chunk as the others
-                constexpr bool pv = pr;
-                f32x16& acc = accp[0];
+                constexpr int t = decltype(TC)::value, sl = t & 1;
                 SLOTSTAMP(i);
                 IRA_WAIT_LGKM();
                 SLOTSTAMP(i);
@@ -516,39 +535,43 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
                 if (pr && t < 8) {
 #pragma unroll
-                    for (int k = 0; k < KPS; ++k) { if (DBG == 15) bq[sl ^ 1][k] = bq[sl][k]; else bq[sl ^ 1][k] = xnl[((wave + 4 * ((t + 1) / 3)) * KS + KPS * ((t + 1) % 3) + k) * 64 + lane]; }
+                    for (int ms = (NMS * t + NMS - 1) / 3 + 1; ms <= (NMS * (t + 1) + NMS - 1) / 3; ++ms) fr[ms] = *frag_ptr(ms);
                 }
                 IRA_PIN();
                 if (un && t == 5) unit_gelu_a(0);
                 if (un && t == 6) { unit_gelu_b(0); unit_gelu_a(4); }
                 if (un && t == 7) unit_gelu_b(4);
-                if (pv) {
-                    if (t % 3 == 0) {
+                if (pr) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            acc[e] = BIN ? bin[16 * i + 8 * h + e] : 0.f;
-                            acc[8 + e] = BIN ? bin[Hp + 16 * i + 8 * h + e] : 0.f;
+                    for (int m = 0; m < NMS; ++m) {
+                        const int q = NMS * t + m, ms = q / 3, gi = q - 3 * ms, ks = ms >> 1;
+                        if (ms == 0) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                accp[gi][e] = BIN ? bin[16 * i + 8 * h + e] : 0.f;
+                                accp[gi][8 + e] = BIN ? bin[Hp + 16 * i + 8 * h + e] : 0.f;
+                            }
                         }
-                    }
+                        if (DBG != 3 && DBG != 14) accp[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ms], xb[gi][ks], accp[gi], 0, 0, 0);
+                        if (un) {
 #pragma unroll
-                    for (int k = 0; k < KPS; ++k) {
-                        const int ks = KPS * (t % 3) + k;
-                        if (DBG != 3 && DBG != 14) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[par][ks], bq[sl][k], acc, 0, 0, 0);
-                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k : 0, t); if (KPS == 1) unit_fma4(sl, 1, t); }
-                        IRA_PIN();
-                        if (DBG != 3 && DBG != 14) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[par][ks], bq[sl][k], acc, 0, 0, 0);
-                        if (un) { unit_fma4(sl, (KPS == 2) ? 2 * k + 1 : 2, t); if (KPS == 1) unit_fma4(sl, 3, t); }
+                            for (int qq = 0; qq < 4 / NMS; ++qq) unit_fma4(sl, m * (4 / NMS) + qq, t);
+                        }
                         IRA_PIN();
                     }
-                    if (t % 3 == 2) write_out(acc, hp, gi);
                 } else {
                     if (un) { unit_fma4(sl, 0, t); unit_fma4(sl, 1, t); unit_fma4(sl, 2, t); unit_fma4(sl, 3, t); }
                 }
             };
             slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{}); slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{}); slot(IC<8>{});
+            if (pr) {
+#pragma unroll
+                for (int gi = 0; gi < 3; ++gi) write_out(accp[gi], hp, gi);
+            }
             STAMP();
             if (un) unit_finish(i - 1);
             STAMP();
+            if (pr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk i + 1's weights has landed (the P waves have no other vector-memory traffic)
             lds_barrier();
             STAMP();
         };
@@ -567,6 +590,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     STAMP();
     __syncthreads();        // (3) done (see the P branch)
     STAMP();
+    lds_barrier();          // (the P waves have taken their pixel fragments out of the xn region)
     half8 fA, fB;
     auto cinterval = [&](auto UNc, auto COc, auto PARc, int i) {
         constexpr bool un_ = decltype(UNc)::value, un = un_ && DBG != 2 && DBG != 12 && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16, co = decltype(COc)::value && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16;
@@ -688,7 +712,7 @@ template <int C, int LN, bool BIN, bool CB, bool FOLD>
 static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
                                int T, int H, int W, int Hp) {
-    constexpr size_t LDS = (size_t)NG * (C / 16) * 1024 + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES;
+    constexpr size_t LDS = (size_t)NG * (C / 16) * 1024 + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES + (size_t)2 * (C / 16) * 1024;   // + weight stage 0
     static_assert(2 * ((C + 31) / 32) * (C / 16) * 1024 <= 2 * HP_BYTES + 2 * G_BYTES, "M staging must fit the hp / g region");
     const float2* tab = nullptr;
     if (hipError_t e = phi_table(&tab); e != hipSuccess) return e;
