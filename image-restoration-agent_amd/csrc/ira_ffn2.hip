@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                                               const f16* __restrict__ Win, const float* __restrict__ bin,
                                               const float* __restrict__ dwu, const float* __restrict__ dwub,
                                               const f16* __restrict__ Wout, const float* __restrict__ bout,
-                                              const float2* __restrict__ phitab, int T, int H, int W, int Hp, int stagger) {
+                                              const float2* __restrict__ phitab, int T, int H, int W, int Hp, int ldo) {
     constexpr int KS = C / 16;            // k-steps of project_in / of the attention apply
     constexpr int NBC = (C + 31) / 32;    // 32-row blocks of project_out / of M
     constexpr size_t XN_BYTES = (size_t)NG * KS * 1024;
@@ -182,15 +182,8 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
 #endif
     };
     STAMP();
-    // Phase stagger.  Every workgroup takes the same time, so without this all 256 CUs run their prologues (130 KB of x each = 33 MB
-    // at once) and then their main loops (no HBM traffic) in lockstep: the prologue is then HBM-bound chip-wide (16-19k cycles
-    // measured for what one CU alone loads in 3k) while the memory system idles for the rest of the patch.  The first block on each
-    // CU starts 0-3 quarter patch times late; its successors on that CU inherit the phase.
-    if (stagger > 0 && blockIdx.x < 256) {
-        const int ph = (blockIdx.x >> 3) & 3;
-        for (int k = 0; k < ph * stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-
+    // (r1-r2 delayed the first workgroup of every CU by 0-3 quarter patch times so that the CUs' prologues would not coincide; since the
+    // weights travel through LDS (r3) the stagger measures nothing: 7.82 / 7.84 / 7.85 / 7.83 ms at 0 / 1 / 3 / 5 units, and it is gone.)
     // pixel of (group g, lane r): in-image flag and pixel offset inside the tile (clamped to pixel 0 when not loadable)
     auto pixel_of = [&](int g, bool& in) -> long {
         const int q = group_q(g, r);
@@ -663,8 +656,8 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                         lo[e] = (rowsel ? accB[nb][8 * u + e] : accA[nb][8 * u + e]) + (CB ? bout[n0 + e] : 0.f);
                         hi[e] = (rowsel ? accB[nb][8 * u + 4 + e] : accA[nb][8 * u + 4 + e]) + (CB ? bout[n0 + 4 + e] : 0.f);
                     }
-                    *(f32x4*)(xo + po * C + n0) = lo;
-                    *(f32x4*)(xo + po * C + n0 + 4) = hi;
+                    *(f32x4*)(xo + po * ldo + n0) = lo;                 // ldo floats per output pixel (C, or the width of a concat buffer)
+                    *(f32x4*)(xo + po * ldo + n0 + 4) = hi;
                 }
             }
     }
@@ -711,7 +704,7 @@ bool ffn2_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0
 template <int C, int LN, bool BIN, bool CB, bool FOLD>
 static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
-                               int T, int H, int W, int Hp) {
+                               int T, int H, int W, int Hp, int ldo) {
     constexpr size_t LDS = (size_t)NG * (C / 16) * 1024 + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES + (size_t)2 * (C / 16) * 1024;   // + weight stage 0
     static_assert(2 * ((C + 31) / 32) * (C / 16) * 1024 <= 2 * HP_BYTES + 2 * G_BYTES, "M staging must fit the hp / g region");
     const float2* tab = nullptr;
@@ -719,8 +712,6 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD>, LDS, attr_done); e != hipSuccess) return e;
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    static const int stagger_env = getenv("IRA_FFN2_STAGGER") ? atoi(getenv("IRA_FFN2_STAGGER")) : 3;   // s_sleep(127) units per phase step
-    const int stagger = nblk >= 1024 ? stagger_env : 0;          // only where a CU runs several patches
 #ifdef IRA_KERNEL_DBG
     if constexpr (C == 96 && LN == 1 && !BIN && !CB && !FOLD) {
         static const int dbg = getenv("IRA_FFN2_DBG") ? atoi(getenv("IRA_FFN2_DBG")) : 0;
@@ -729,7 +720,7 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
         static std::atomic<uint64_t> ad{0};                                                                                                     \
         if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD, D_>, LDS, ad); e != hipSuccess) return e;                \
         hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD, D_>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, \
-                           dww, dwb, Wout, bout, tab, T, H, W, Hp, stagger);                                                                    \
+                           dww, dwb, Wout, bout, tab, T, H, W, Hp, ldo);                                                                    \
         return hipGetLastError();                                                                                                               \
     }
         IRA_DBG_LAUNCH(1) IRA_DBG_LAUNCH(2) IRA_DBG_LAUNCH(3) IRA_DBG_LAUNCH(4) IRA_DBG_LAUNCH(5) IRA_DBG_LAUNCH(6) IRA_DBG_LAUNCH(7) IRA_DBG_LAUNCH(8) IRA_DBG_LAUNCH(9) IRA_DBG_LAUNCH(12) IRA_DBG_LAUNCH(13) IRA_DBG_LAUNCH(14) IRA_DBG_LAUNCH(15) IRA_DBG_LAUNCH(16)
@@ -737,17 +728,17 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
     }
 #endif
     hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
-                       Wout, bout, tab, T, H, W, Hp, stagger);
+                       Wout, bout, tab, T, H, W, Hp, ldo);
     return hipGetLastError();
 }
 
 template <int C, int LN, bool FOLD>
 static hipError_t ffn2_launch2(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
-                               int T, int H, int W, int Hp) {
+                               int T, int H, int W, int Hp, int ldo) {
     const bool cb = dwb != nullptr && bout != nullptr;
     if ((dwb != nullptr) != (bout != nullptr)) return hipErrorInvalidValue;
-#define IRA_F2(BIN_, CB_) return ffn2_launch3<C, LN, BIN_, CB_, FOLD>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp)
+#define IRA_F2(BIN_, CB_) return ffn2_launch3<C, LN, BIN_, CB_, FOLD>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo)
     if (bin) { if (cb) IRA_F2(true, true); else IRA_F2(true, false); }
     else { if (cb) IRA_F2(false, true); else IRA_F2(false, false); }
 #undef IRA_F2
@@ -756,8 +747,8 @@ static hipError_t ffn2_launch2(hipStream_t st, const float* x, float* xo, const 
 template <int C>
 static hipError_t ffn2_launch1(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                int ln_mode, const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout,
-                               const float* bout, int T, int H, int W, int Hp) {
-#define IRA_F1(LN_, FOLD_) return ffn2_launch2<C, LN_, FOLD_>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp)
+                               const float* bout, int T, int H, int W, int Hp, int ldo) {
+#define IRA_F1(LN_, FOLD_) return ffn2_launch2<C, LN_, FOLD_>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo)
     if (ln_mode == 1) { if (v) IRA_F1(1, true); else IRA_F1(1, false); }
     else { if (v) IRA_F1(2, true); else IRA_F1(2, false); }
 #undef IRA_F1
@@ -765,10 +756,12 @@ static hipError_t ffn2_launch1(hipStream_t st, const float* x, float* xo, const 
 
 hipError_t launch_ffn2(hipStream_t st, const float* x, float* xo, const void* v, const void* M, long m_tile_stride, const float* wo_b,
                        int ln_mode, int C, const void* Win, const float* bin, const float* dww, const float* dwb, const void* Wout,
-                       const float* bout, int T, int H, int W, int Hp) {
+                       const float* bout, int T, int H, int W, int Hp, int ldo) {
+    if (ldo == 0) ldo = C;
+    if (ldo < C || (ldo & 3)) return hipErrorInvalidValue;
     if (x == xo || (ln_mode != 1 && ln_mode != 2) || !ffn2_supported(C, Hp) || ((v != nullptr) != (M != nullptr))) return hipErrorInvalidValue;
-    if (C == 48) return ffn2_launch1<48>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
-    return ffn2_launch1<96>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp);
+    if (C == 48) return ffn2_launch1<48>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo);
+    return ffn2_launch1<96>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo);
 }
 
 }  // namespace ira

@@ -120,6 +120,7 @@ struct ira_model {
     float *ae1, *ad1, *ae2, *ad2;     // ping-pong partners of the residual stream (fused FFN writes out of place)
     bool use_fused_ffn = true;
     int ffn_gen = 2;
+    float* ffn_out = nullptr; int ffn_out_ld = 0;     // one-shot output override of the next fused GDFN launch (ira_rt_restormer.hip: level-1 concat without a copy)
     char* lo_backup = nullptr;           // device copy of the lo planes that w_planes == 1 zeroed (ira_set_weight_planes(2) puts them back)
     int w_planes = 2;          // ira_set_weight_planes: 1 = the 1x1 layers of this model use the hi plane alone where a kernel for that exists                  // 2: ira_ffn2.hip (attention apply folded in); 1: ira_ffn_fused.hip + separate apply (IRA_FFN_GEN=1)
     // strip-parallel whole-frame forward (ira_strip_*): this rank's band of rows with halo rows of its neighbours

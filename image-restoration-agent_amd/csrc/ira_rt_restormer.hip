@@ -213,8 +213,13 @@ static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const fl
     if (ffn2_usable(m, dw_u, dw_ub, dw_b, alt, C, Hp)) {
         char kf[64];
         if (m->profile) snprintf(kf, sizeof kf, "%s|C%d|%dx%d|T%d", v ? "attn_ffn_fused" : "ffn_fused", C, H, W, T); else kf[0] = 0;
-        RUN(m, kf, ira::launch_ffn2(st, x, alt, v, M, m_stride, wo_b, ln, C, pin_w, pin_b, dw_u, dw_b ? dw_ub : nullptr, pout_w, pout_b, T, H, W, Hp));
-        std::swap(x, alt);
+        // (m->ffn_out: the caller wants THIS block's output somewhere else, with its own pixel stride: the last block of encoder level 1 writes
+        // straight into the skip half of decoder level 1's concat buffer.  One shot: cleared here.)
+        float* dst = m->ffn_out ? m->ffn_out : alt;
+        const int ldo = m->ffn_out ? m->ffn_out_ld : 0;
+        RUN(m, kf, ira::launch_ffn2(st, x, dst, v, M, m_stride, wo_b, ln, C, pin_w, pin_b, dw_u, dw_b ? dw_ub : nullptr, pout_w, pout_b, T, H, W, Hp, ldo));
+        if (m->ffn_out) { x = dst; m->ffn_out = nullptr; }
+        else std::swap(x, alt);
         return IRA_OK;
     }
     if (v != nullptr) return m->fail(IRA_ERR_ARG, "run_ffn: attention fold requested without the second-generation fused kernel");
@@ -379,9 +384,23 @@ int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W
 
     float *e1 = m->xe1, *e2 = m->xe2, *e3 = m->xe3, *l4 = m->x4, *d3 = m->xd3, *d2 = m->xd2, *d1 = m->xd1;
     RUN(m, "embed3x3", ira::launch_embed(st, in, m->embed_w, m->embed_b, e1, T, g.H[0], g.W[0], c.inp_channels, g.C[0]));            // :247
-    if ((rc = run_stage(m, m->enc1, e1, m->ae1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0], 0))) return rc;                         // :248
+    // torch.cat([up2_1(d2), e1], 1) (:269-270) without a copy: where the fused GDFN kernel ends the blocks of encoder level 1, the LAST of them
+    // writes e1 straight into channels C .. 2C-1 of decoder level 1's 2C-wide buffer (pixel stride 2C), and the down-convolution reads it there
+    int e1_ld = g.C[0];
+    {
+        const std::vector<Blk>& blks = m->enc1;
+        const bool direct = !m->strip_on && !m->xr && !blks.empty() &&
+                            ffn2_usable(m, blks.back().dw2_u, blks.back().dw2_ub, blks.back().dw2_b, m->ae1, g.C[0], g.Hp[0]);
+        float* alt1 = m->ae1;
+        for (size_t bi = 0; bi < blks.size(); ++bi) {                                                                                         // :248
+            if (direct && bi + 1 == blks.size()) { m->ffn_out = d1 + g.C[0]; m->ffn_out_ld = 2 * g.C[0]; e1_ld = 2 * g.C[0]; }
+            if ((rc = run_block(m, blks[bi], e1, alt1, T, g.H[0], g.W[0], g.C[0], g.heads[0], g.Hp[0], 0))) { m->ffn_out = nullptr; return rc; }
+        }
+        m->ffn_out = nullptr;
+    }
     if ((rc = strip_halo(m, e1, g.H[0], g.W[0], g.C[0], 0))) return rc;
-    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2)));   // :250
+    RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e1, m->down12, nullptr, nullptr, e2, 1, T, g.H[0], g.W[0], g.C[0], g.C[0] / 2, nb(g.C[0] / 2), 0.f,
+                                               e1_ld == g.C[0] ? 0 : e1_ld));   // :250
     if ((rc = run_stage(m, m->enc2, e2, m->ae2, T, g.H[1], g.W[1], g.C[1], g.heads[1], g.Hp[1], 1))) return rc;
     if ((rc = strip_halo(m, e2, g.H[1], g.W[1], g.C[1], 1))) return rc;
     RUN(m, "conv3x3_down", ira::launch_conv3x3(st, e2, m->down23, nullptr, nullptr, e3, 1, T, g.H[1], g.W[1], g.C[1], g.C[1] / 2, nb(g.C[1] / 2)));
@@ -402,7 +421,7 @@ int restormer_forward_enqueue(ira_model* m, const float* in, int T, int H, int W
     // torch.cat([up2_1(d2), e1], 1) (:269-270): the up-convolution's PixelShuffle epilogue writes its half straight into the first C
     // channels of the 2C-wide buffer, only the skip half is copied
     RUN(m, "conv3x3_up", ira::launch_conv3x3(st, d2, m->up21, nullptr, nullptr, d1, 2, T, g.H[1], g.W[1], g.C[1], g.C[1] * 2, nb(g.C[1] * 2), 0.f, 0, 2 * g.C[0]));
-    RUN(m, "concat", ira::launch_copy_slice(st, e1, g.C[0], d1, 2 * g.C[0], g.C[0], (long)T * g.P[0]));
+    if (e1_ld == g.C[0]) RUN(m, "concat", ira::launch_copy_slice(st, e1, g.C[0], d1, 2 * g.C[0], g.C[0], (long)T * g.P[0]));      // (else e1 already lies there)
     float* a1 = m->ad1;
     if ((rc = run_stage(m, m->dec1, d1, a1, T, g.H[0], g.W[0], g.C[1], g.heads[0], g.Hp[1], 0))) return rc;                              // :271
     a1 = (d1 == m->xd1) ? m->ad1 : m->xd1;
