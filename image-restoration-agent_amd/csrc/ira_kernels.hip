@@ -457,11 +457,9 @@ __device__ __forceinline__ void dw_block(const f16* __restrict__ in, const float
         for (int dx = 0; dx < 3; ++dx) {
             const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
             const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
-            float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+            // (v_fma_mix_f32: as (float)half * w + a the compiler emitted v_cvt_f32_f16 + v_pk_fma_f32 + moves, twice the vector instructions)
 #pragma unroll
-            for (int p = 0; p < PX; ++p)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[p + dx][e], wv[e], acc[p][e]);
+            for (int p = 0; p < PX; ++p) dw_tap(acc[p], __builtin_bit_cast(u32x4, v[p + dx]), wl, wh);
         }
     }
     if (bias != nullptr) {
@@ -505,11 +503,8 @@ __device__ __forceinline__ void dw_block2(const f16* __restrict__ in, const floa
             for (int dx = 0; dx < 3; ++dx) {
                 const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
                 const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
-                float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
 #pragma unroll
-                for (int p = 0; p < PX; ++p)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o][p][e] = fmaf((float)v[p + dx][e], wv[e], acc[o][p][e]);
+                for (int p = 0; p < PX; ++p) dw_tap(acc[o][p], __builtin_bit_cast(u32x4, v[p + dx]), wl, wh);
             }
         }
     }
@@ -717,15 +712,13 @@ __global__ __launch_bounds__(256) void k_dwconv_gate_row(const f16* __restrict__
             for (int dx = 0; dx < 3; ++dx) {
                 const f32x4 w1l = *(const f32x4*)&wsm[dy * 3 + dx][lane][0], w1h = *(const f32x4*)&wsm[dy * 3 + dx][lane][4];
                 const f32x4 w2l = *(const f32x4*)&wsm[9 + dy * 3 + dx][lane][0], w2h = *(const f32x4*)&wsm[9 + dy * 3 + dx][lane][4];
+                // v_fma_mix_f32 (fp16 source, fp32 weight and sum: the same arithmetic): written as (float)half * w + a the compiler made
+                // v_cvt_f32_f16 + v_pk_fma_f32 + moves of it, twice the vector instructions (r3: 0.53 -> see DESIGN 5 ms per level-3 launch)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a1[p][e] = fmaf((float)v1[p + dx][e], w1l[e], a1[p][e]);
-                        a1[p][4 + e] = fmaf((float)v1[p + dx][4 + e], w1h[e], a1[p][4 + e]);
-                        a2[p][e] = fmaf((float)v2[p + dx][e], w2l[e], a2[p][e]);
-                        a2[p][4 + e] = fmaf((float)v2[p + dx][4 + e], w2h[e], a2[p][4 + e]);
-                    }
+                for (int p = 0; p < 4; ++p) {
+                    dw_tap(a1[p], __builtin_bit_cast(u32x4, v1[p + dx]), w1l, w1h);
+                    dw_tap(a2[p], __builtin_bit_cast(u32x4, v2[p + dx]), w2l, w2h);
+                }
             }
         }
         f16* dst = out + ((long)(t * H + y) * W + x0) * Hp + g * 8;

@@ -348,11 +348,9 @@ IRA_DEV void naf_dw_block(const f16* __restrict__ in, const float* __restrict__ 
         for (int dx = 0; dx < 3; ++dx) {
             const float* wp = w + (long)(dy * 3 + dx) * Cs + ch0;
             const f32x4 wl = *(const f32x4*)wp, wh = *(const f32x4*)(wp + 4);
-            const float wv[8] = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+            // (v_fma_mix_f32: as (float)half * w + a the compiler emitted v_cvt_f32_f16 + v_pk_fma_f32 + moves, twice the vector instructions)
 #pragma unroll
-            for (int p = 0; p < PX; ++p)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[p][e] = fmaf((float)v[p + dx][e], wv[e], acc[p][e]);
+            for (int p = 0; p < PX; ++p) dw_tap(acc[p], __builtin_bit_cast(u32x4, v[p + dx]), wl, wh);
         }
     }
 }
