@@ -54,10 +54,10 @@ hipError_t launch_qkv_fused(hipStream_t st, const float* x, int ln_mode, int C, 
 // q,k elements); weights staged once per workgroup in LDS by DMA; MFMAs and depthwise FMAs interleaved.  Same arguments, layouts and
 // rounding points as generation 1.  launch_qkv_front picks the generation: 3 unless IRA_QKV_GEN=1 (read once per process).
 hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
-                            const float* dwb, void* qk, void* v, int T, int H, int W);
+                            const float* dwb, void* qk, void* v, int T, int H, int W, int planes = 2);   // planes 1: generation 3 skips the lo weight plane
 bool qkv3_supported(int C);
 hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
-                       const float* dwb, void* qk, void* v, int T, int H, int W);
+                       const float* dwb, void* qk, void* v, int T, int H, int W, int planes = 2);
 
 // Fused GDFN (ira_ffn_fused.hip): x_out = x + ffn(LN(x)); x_out must not alias x.  Supported for C in {48, 96}.
 bool ffn_fused_supported(int C, int Hp);

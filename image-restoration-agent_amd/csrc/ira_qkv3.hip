@@ -84,7 +84,10 @@ __device__ unsigned long long g_qkv3_stamps[64];        // s_memtime of wave 0 o
 
 // DBG (measurement variants, wrong results; instantiated and selectable - IRA_QKV3_DBG - only in the `make dbg` library): 1 = no global
 // stores, 2 = no pixel loads, 4 = no MFMAs, 8 = no depthwise FMAs, 16 = no LDS traffic of the hidden tile (bits may be combined)
-template <int C, int LN, bool BIN, bool CB, int DBG = 0>
+// LO: the 1x1 weights have a lo plane (fp16 hi + lo, two MFMAs per fragment); false = plain fp16 weights, half the MFMAs and half the staged
+// bytes - the handle's default since r3 (ira_set_weight_planes(1); the qkv 1x1 only feeds the Gram / softmax: dropping its lo plane moves the
+// worst |dPSNR| of the 27 harness / sweep / bench-tile cases from 5.5e-4 to 5.7e-4 dB, tools/ablate_lo_restormer.py)
+template <int C, int LN, bool BIN, bool CB, int DBG = 0, bool LO = true>
 __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x, const f16* __restrict__ Wq, const float* __restrict__ bq,
                                                      const float* __restrict__ dww, const float* __restrict__ dwb, f16* __restrict__ qk,
                                                      f16* __restrict__ vout, int T, int H, int W) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
     // (each wave moves its share), one interval ahead, into stage j & 1; every wave reads them from there, one ds_read_b128 per MFMA.  In
     // registers (one private copy per wave, generation 1 / 2 and the first form of this kernel) they were 48 registers per set, four times
     // the L2 traffic, and with a single set the request could only be issued behind the last MFMA: its latency (~5k cycles under load) lay open.
-    constexpr int NF = 2 * KS;
+    constexpr int NF = LO ? 2 * KS : KS;
     constexpr size_t WST = (size_t)NF * 1024;
     char* wst = smem + Q3_MAIN;                        // [2][NF][64 lanes][16 B]
     float bias1[2];
@@ -424,9 +427,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_qkv3(const float* __restrict__ x
         };
         [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
             ([&] {
-                constexpr int q = Q, ms = q / 3, gi = q % 3, sk = ms >> 1;       // fragment ms: k-step sk, plane ms & 1 (hi, then lo: the order of the other generations)
+                constexpr int q = Q, ms = q / 3, gi = q % 3, sk = LO ? ms >> 1 : ms;       // fragment ms: k-step sk, plane ms & 1 (hi, then lo: the order of the other generations)
                 if constexpr (pr) {
-                    if constexpr (gi == 0 && ms + 1 < NF) { constexpr int msn = ms + 1, fn = (msn & 1) * KS + (msn >> 1); bwn = *(const half8*)(wcur + fn * 1024); }
+                    if constexpr (gi == 0 && ms + 1 < NF) { constexpr int msn = ms + 1, fn = LO ? (msn & 1) * KS + (msn >> 1) : msn; bwn = *(const half8*)(wcur + fn * 1024); }
                     if constexpr (DBG & 4) asm volatile("" :: "v"(xa[gi][sk]), "v"(bw));
                     else acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[gi][sk], bw, acc[gi], 0, 0, 0);
                     if constexpr (gi == 2) bw = bwn;
@@ -473,13 +476,13 @@ extern "C" int ira_debug_qkv3_stamps(unsigned long long* out) {
 
 bool qkv3_supported(int C) { return C == 48 || C == 96; }
 
-template <int C, int LN, bool BIN, bool CB>
-static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww, const float* dwb, f16* qk,
+template <int C, int LN, bool BIN, bool CB, bool LO>
+static hipError_t qkv3_launch3(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww, const float* dwb, f16* qk,
                                f16* v, int T, int H, int W) {
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    constexpr size_t LDS = Q3_MAIN + 2 * (2 * (C / 16)) * 1024;
+    constexpr size_t LDS = Q3_MAIN + 2 * ((LO ? 2 : 1) * (C / 16)) * 1024;
 #ifdef IRA_KERNEL_DBG
-    if constexpr (C == 96 && LN == 1 && !BIN && !CB) {
+    if constexpr (C == 96 && LN == 1 && !BIN && !CB && LO) {
         static const int dbg = getenv("IRA_QKV3_DBG") ? atoi(getenv("IRA_QKV3_DBG")) : 0;
 #define IRA_Q3_DBG(D_)                                                                                                                   \
     if (dbg == D_) {                                                                                                                      \
@@ -493,15 +496,22 @@ static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, co
     }
 #endif
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB>, LDS, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB>), dim3((unsigned)nblk), dim3(64 * NW), LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_qkv3<C, LN, BIN, CB, 0, LO>, LDS, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_qkv3<C, LN, BIN, CB, 0, LO>), dim3((unsigned)nblk), dim3(64 * NW), LDS, st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
     return hipGetLastError();
+}
+
+template <int C, int LN, bool BIN, bool CB>
+static hipError_t qkv3_launch2(hipStream_t st, const float* x, const f16* Wq, const float* bq, const float* dww, const float* dwb, f16* qk,
+                               f16* v, int T, int H, int W, int planes) {
+    if (planes == 1) return qkv3_launch3<C, LN, BIN, CB, false>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
+    return qkv3_launch3<C, LN, BIN, CB, true>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W);
 }
 
 template <int C>
 static hipError_t qkv3_launch(hipStream_t st, const float* x, int ln_mode, const f16* Wq, const float* bq, const float* dww, const float* dwb,
-                              f16* qk, f16* v, int T, int H, int W) {
-#define IRA_QKV3(LN_, BIN_, CB_) return qkv3_launch2<C, LN_, BIN_, CB_>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W)
+                              f16* qk, f16* v, int T, int H, int W, int planes) {
+#define IRA_QKV3(LN_, BIN_, CB_) return qkv3_launch2<C, LN_, BIN_, CB_>(st, x, Wq, bq, dww, dwb, qk, v, T, H, W, planes)
     if (ln_mode == 1) {
         if (bq) { if (dwb) IRA_QKV3(1, true, true); else IRA_QKV3(1, true, false); }
         else { if (dwb) IRA_QKV3(1, false, true); else IRA_QKV3(1, false, false); }
@@ -513,18 +523,18 @@ static hipError_t qkv3_launch(hipStream_t st, const float* x, int ln_mode, const
 }
 
 hipError_t launch_qkv3(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
-                       const float* dwb, void* qk, void* v, int T, int H, int W) {
-    if ((ln_mode != 1 && ln_mode != 2) || !qkv3_supported(C)) return hipErrorInvalidValue;
-    if (C == 48) return qkv3_launch<48>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
-    return qkv3_launch<96>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W);
+                       const float* dwb, void* qk, void* v, int T, int H, int W, int planes) {
+    if ((ln_mode != 1 && ln_mode != 2) || !qkv3_supported(C) || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
+    if (C == 48) return qkv3_launch<48>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W, planes);
+    return qkv3_launch<96>(st, x, ln_mode, (const f16*)Wq, bq, dww, dwb, (f16*)qk, (f16*)v, T, H, W, planes);
 }
 
 // The network schedule's entry: generation 3 unless IRA_QKV_GEN=1 (A/B on the same box; read once per process).
 hipError_t launch_qkv_front(hipStream_t st, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
-                            const float* dwb, void* qk, void* v, int T, int H, int W) {
+                            const float* dwb, void* qk, void* v, int T, int H, int W, int planes) {
     static const int gen = getenv("IRA_QKV_GEN") ? atoi(getenv("IRA_QKV_GEN")) : 3;
     if (gen == 1) return launch_qkv_fused(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
-    return launch_qkv3(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W);
+    return launch_qkv3(st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W, planes);
 }
 
 }  // namespace ira

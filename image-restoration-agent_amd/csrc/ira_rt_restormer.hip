@@ -175,8 +175,13 @@ void restormer_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& ou
     for (int si = 0; si < 8; ++si) {
         const int l = lvl[si];
         const int C = (si >= 6) ? (c.dim << 1) : (c.dim << l);        // decoder level 1 and the refinement stage run at 2 * dim
-        if (!hi_plane_level(C)) continue;
         const size_t Hp = up32((si >= 6) ? c.hidden[1] : c.hidden[l]), NBq = up32(3 * C), NBc = up32(C);
+        if (!hi_plane_level(C)) {
+            // levels of the fused kernels (r3): the qkv 1x1 alone (k_qkv3 skips its lo plane; project_in / project_out keep theirs: their lo
+            // planes cost 4-5e-4 dB of the 1e-3 bar, tools/ablate_lo_restormer.py)
+            if (ira::qkv3_supported(C)) for (Blk& b : *stages[si]) add(b.qkv_w, 2 * NBq * C * 2);
+            continue;
+        }
         for (Blk& b : *stages[si]) {
             add(b.qkv_w, 2 * NBq * C * 2);
             add(b.pin_w, (size_t)2 * 2 * Hp * C * 2);
@@ -310,7 +315,7 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
     if (m->use_fused_ffn && ira::qkv_fused_supported(C)) {
         char kq[64];
         if (m->profile) snprintf(kq, sizeof kq, "qkv_fused|C%d|%dx%d|T%d", C, H, W, T); else kq[0] = 0;
-        RUN(m, kq, ira::launch_qkv_front(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W));
+        RUN(m, kq, ira::launch_qkv_front(st, x, ln, C, b.qkv_w, b.qkv_b, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, m->w_planes));
     } else {
         RUN(m, k_[0], ira::launch_pw_kres(st, x, true, ln, C, b.qkv_w, b.qkv_b, m->qkvp, 3 * C, 3 * C, NBq, T, P, 1e-5f, 0, 0, hi_plane_level(C) ? m->w_planes : 2));
         RUN(m, k_[1], ira::launch_dwconv_qkv(st, m->qkvp, b.dw1_w, b.dw1_b, m->qk, m->v, T, H, W, C));

@@ -1036,14 +1036,14 @@ int ira_set_ffn_generation(ira_model_t* m, int gen) {
 
 int ira_op_qkv_fused(ira_model_t* m, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                      const float* dwb, void* qk, void* v, int T, int H, int W) {
-    OP_BODY(m, "op", ira::launch_qkv_front(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W));
+    OP_BODY(m, "op", ira::launch_qkv_front(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W, m->w_planes));
 }
 
 int ira_op_qkv_fused_gen(ira_model_t* m, int gen, const float* x, int ln_mode, int C, const void* Wq, const float* bq, const float* dww,
                          const float* dwb, void* qk, void* v, int T, int H, int W) {
     if (m && gen != 1 && gen != 3) return m->fail(IRA_ERR_ARG, "ira_op_qkv_fused_gen: generation 1 or 3");
     OP_BODY(m, "op", gen == 1 ? ira::launch_qkv_fused(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W)
-                              : ira::launch_qkv3(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W));
+                              : ira::launch_qkv3(m->st, x, ln_mode, C, Wq, bq, dww, dwb, qk, v, T, H, W, m->w_planes));
 }
 
 int ira_set_fused_ffn(ira_model_t* m, int on) {

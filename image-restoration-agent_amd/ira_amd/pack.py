@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import struct
 
+import os
+
 import numpy as np
 
 from .config import RestormerConfig
@@ -108,8 +110,18 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     wq = _np(sd[f'{p}.attn.qkv.weight'])[:, :, 0, 0].astype(np.float64)          # [3C][C]
     wi = _np(sd[f'{p}.ffn.project_in.weight'])[:, :, 0, 0].astype(np.float64)    # [2hid][C]
 
-    out[f'{name}.qkv_w'] = frag_major(split16(_pad_rows(wq * g1[None, :], up32(3 * dim))))
-    out[f'{name}.pin_w'] = frag_major(split16(_hidden_remap(wi * g2[None, :], hid, hp)))
+    # IRA_ABLATE_LO_L12 (accuracy ablation, tools/ablate_lo_restormer.py): comma list of {qkv, pin, pout}: the lo planes of those 1x1 weights are
+    # zeroed on the levels the fused kernels run (dim in {48, 96}) - numerically what a kernel that skips the lo-plane MFMAs computes
+    abl = set(filter(None, os.environ.get('IRA_ABLATE_LO_L12', '').split(','))) if dim in (48, 96) else set()
+
+    def planes(a, kind):
+        sp = split16(a)
+        if kind in abl:
+            sp[1] = 0
+        return frag_major(sp)
+
+    out[f'{name}.qkv_w'] = planes(_pad_rows(wq * g1[None, :], up32(3 * dim)), 'qkv')
+    out[f'{name}.pin_w'] = planes(_hidden_remap(wi * g2[None, :], hid, hp), 'pin')
     bq = np.zeros(3 * dim, np.float64)
     bi = np.zeros(2 * hid, np.float64)
     has_b = False
@@ -132,7 +144,7 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
     out[f'{name}.wo'] = np.ascontiguousarray(_np(sd[f'{p}.attn.project_out.weight'])[:, :, 0, 0])
     wout = np.zeros((up32(dim), hp), np.float64)
     wout[:dim, :hid] = _np(sd[f'{p}.ffn.project_out.weight'])[:, :, 0, 0]
-    out[f'{name}.pout_w'] = frag_major(split16(wout))
+    out[f'{name}.pout_w'] = planes(wout, 'pout')
     if cfg.bias:
         out[f'{name}.dw1_b'] = _np(sd[f'{p}.attn.qkv_dwconv.bias']).astype(np.float32)
         out[f'{name}.dw2_b'] = _hidden_remap(_np(sd[f'{p}.ffn.dwconv.bias']).astype(np.float32), hid, hp)

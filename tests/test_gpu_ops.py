@@ -727,3 +727,54 @@ def test_qkv3_equals_generation1(ctx, C, ln, T, H, W, bias, GEN_NEW):
         # one fp16 ulp of a hidden value of magnitude < 8 is 2^-8 at most; a depthwise weight is < 2 here
         print(f"{name}: {ndiff} of {a.numel()} elements differ, max |delta| {float(df.max()):.3e}")
         assert ndiff < 1e-3 * a.numel() and float(df.max()) <= 2 ** -7, (name, ndiff, float(df.max()))
+
+
+@pytest.mark.parametrize('C,ln,T,H,W,bias', [(96, 1, 2, 24, 70, False), (48, 2, 1, 17, 41, True)])
+def test_qkv3_hi_plane_only(ctx, C, ln, T, H, W, bias):
+    """ira_set_weight_planes(1), the handles' default (r3): k_qkv3 reads the hi plane of the qkv 1x1 alone.  That is, to the bit, what the
+    two-plane kernel computes on a blob whose lo plane is zero (x * 0 adds nothing) - the identity the accuracy ablation
+    (tools/ablate_lo_restormer.py) and the handle's zeroed lo planes rest on."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    g = torch.Generator().manual_seed(3 * C + ln + W)
+    hid = 32
+    sd = {
+        'b.norm1.body.weight': 1 + 0.1 * torch.randn(C, generator=g), 'b.norm2.body.weight': torch.ones(C),
+        'b.attn.temperature': torch.ones(1, 1, 1), 'b.attn.qkv.weight': torch.randn(3 * C, C, 1, 1, generator=g) / C ** 0.5,
+        'b.attn.qkv_dwconv.weight': torch.randn(3 * C, 1, 3, 3, generator=g) / 3,
+        'b.attn.project_out.weight': torch.zeros(C, C, 1, 1),
+        'b.ffn.project_in.weight': torch.zeros(2 * hid, C, 1, 1), 'b.ffn.dwconv.weight': torch.zeros(2 * hid, 1, 3, 3),
+        'b.ffn.project_out.weight': torch.zeros(C, hid, 1, 1),
+    }
+    if ln == 2:
+        sd['b.norm1.body.bias'] = 0.1 * torch.randn(C, generator=g)
+        sd['b.norm2.body.bias'] = torch.zeros(C)
+    if bias:
+        for k, n in [('attn.qkv', 3 * C), ('attn.qkv_dwconv', 3 * C), ('attn.project_out', C), ('ffn.project_in', 2 * hid),
+                     ('ffn.dwconv', 2 * hid), ('ffn.project_out', C)]:
+            sd[f'b.{k}.bias'] = 0.1 * torch.randn(n, generator=g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree' if ln == 1 else 'WithBias', bias=bias)
+    cfg.hidden = lambda d_: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    wz = arrs['b.qkv_w'].copy()
+    assert wz.shape[0] == 2
+    wz[1] = 0                                          # the blob with a zero lo plane
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
+    wzd = dev(torch.from_numpy(np.ascontiguousarray(wz)))
+    xd = (torch.randn(T, H, W, C, generator=g) * 1.5).cuda()
+    WB = (W + 7) // 8
+
+    def run(be, w):
+        qk = torch.full((T, H, WB, 2 * C, 8), float('nan'), dtype=torch.float16).cuda()
+        v = torch.full((T, H, W, C), float('nan'), dtype=torch.float16).cuda()
+        rc = be._lib.ira_op_qkv_fused_gen(be.handle, 3, ptr(xd), ln, C, ptr(w), ptr(d.get('b.qkv_b')), ptr(d['b.dw1_w']), ptr(d.get('b.dw1_b')),
+                                          ptr(qk), ptr(v), T, H, W)
+        assert rc == 0, be._lib.ira_last_error(be.handle)
+        torch.cuda.synchronize()
+        return qk, v
+    q2, v2 = run(ctx, wzd)                             # two-plane kernel, zero lo plane
+    with _hi_plane_ctx() as c1:
+        q1, v1 = run(c1, d['b.qkv_w'])                 # hi-plane kernel on the full blob
+    assert torch.isfinite(q1.float()).all() and torch.isfinite(v1.float()).all()
+    assert torch.equal(q1.view(torch.int16), q2.view(torch.int16)) and torch.equal(v1.view(torch.int16), v2.view(torch.int16))

@@ -1,0 +1,50 @@
+"""Accuracy of plain fp16 weights (no lo plane) in the 1x1 layers of Restormer levels 1-2 (dim 48 / 96: the levels of the fused kernels),
+measured ON THE GPU through the harness: for each ablation set, |PSNR(build, clean) - PSNR(oracle, clean)| on the reference-generated
+harness goldens, the 18 robustness-sweep goldens and three 512^2 tiles of the benchmark frame (oracle on the CPU).  Zeroing the lo planes
+in the blob (IRA_ABLATE_LO_L12, ira_amd/pack.py) is numerically what a kernel that skips the lo-plane MFMAs computes.
+usage: python tools/ablate_lo_restormer.py [sets ...]   e.g.  '' qkv pin qkv,pin qkv,pin,pout"""
+import glob, json, os, sys
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(R, 'image-restoration-agent_amd')); sys.path.insert(0, R)
+import numpy as np, torch
+torch.set_num_threads(16)
+from ira_amd.backend import RestormerBackend
+from ira_amd.config import RestormerConfig, task_config
+from ira_amd.weights import seeded_state_dict, to_torch
+from oracle import restormer_oracle as O
+
+GOLD = os.path.join(R, 'tests', 'golden')
+files = sorted(glob.glob(os.path.join(GOLD, 'harness_*.npz'))) + sorted(glob.glob(os.path.join(GOLD, 'sweep_*.npz')))
+sets = sys.argv[1:] or ['', 'qkv', 'pin', 'pout', 'qkv,pin', 'qkv,pin,pout']
+# benchmark tiles: oracle once
+cfgB = task_config('Real_Denoising'); sdB = seeded_state_dict(cfgB, 0)
+clean, noisy = O.synthetic_noisy_image(2160, 3840, 3, sigma=25.0, seed=0)
+tiles = [(0, 0), (960, 1440), (1648, 3328)]
+refB = []
+for (y0, x0) in tiles:
+    refB.append(O.restore_image(noisy[y0:y0 + 512, x0:x0 + 512], to_torch(sdB), cfgB.to_dict()))
+    print('oracle tile', y0, x0, 'done', flush=True)
+for st in sets:
+    os.environ['IRA_ABLATE_LO_L12'] = st
+    worst = 0.0; rows = []
+    for f in files:
+        z = np.load(f, allow_pickle=False)
+        cfg = RestormerConfig(**json.loads(str(z['cfg'])))
+        kw = {}
+        if 'residual_scale' in z.files: kw['residual_scale'] = float(z['residual_scale'])
+        sd = seeded_state_dict(cfg, int(z['seed']), **kw)
+        with RestormerBackend(cfg, sd, device=0) as be:
+            tile = int(z['tile']) if int(z['tile']) > 0 else None
+            out = be.restore(z['noisy'], tile=tile, tile_overlap=int(z['overlap']))
+        ref = z['restored']; cl = z['clean']
+        d = O.psnr_u8(out, cl) - O.psnr_u8(ref, cl)
+        rows.append((os.path.basename(f), d, int(np.abs(out.astype(int) - ref.astype(int)).max())))
+        worst = max(worst, abs(d))
+    with RestormerBackend(cfgB, sdB, device=0) as be:
+        for (y0, x0), rf in zip(tiles, refB):
+            out = be.restore(noisy[y0:y0 + 512, x0:x0 + 512])
+            cl = clean[y0:y0 + 512, x0:x0 + 512]
+            d = O.psnr_u8(out, cl) - O.psnr_u8(rf, cl)
+            rows.append((f'bench tile {y0},{x0}', d, int(np.abs(out.astype(int) - rf.astype(int)).max())))
+            worst = max(worst, abs(d))
+    print(f"ablate [{st}]: worst |dPSNR| {worst:.2e} dB over {len(rows)} cases; the five worst:", sorted(rows, key=lambda r: -abs(r[1]))[:5], flush=True)
