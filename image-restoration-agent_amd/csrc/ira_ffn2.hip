@@ -138,7 +138,10 @@ IRA_DEV float gelu_gate_tab(float a, float b, const float2* tab) {
 __device__ unsigned long long g_ffn2_stamps[2][64];
 #endif
 
-template <int C, int LN, bool BIN, bool CB, bool FOLD, int DBG = 0>
+// LOI / LOO: W_in / W_out carry an fp16 lo plane (hi + lo reproduce the fp32 weight to 2^-22) that the kernel multiplies as well.  false: the
+// plain-fp16 form for the stages whose lo planes the handle has zeroed (weight_planes == 1): half the MFMAs of that 1x1, and
+// bit for bit what the two-plane form computes on the zeroed plane (x + 0 * w = x).
+template <int C, int LN, bool BIN, bool CB, bool FOLD, int DBG = 0, bool LOI = true, bool LOO = true>
 __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float* __restrict__ xo, const f16* __restrict__ v,
                                               const f16* __restrict__ M, long m_stride, const float* __restrict__ wob,
                                               const f16* __restrict__ Win, const float* __restrict__ bin,
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // three groups - stay in 72 registers for the whole patch.  Before (r2): weights in two register sets of 48 per P wave (four private copies
     // from L2 per chunk) and one ds_read_b128 of a pixel fragment per MFMA pair.  Stage 0 lies behind the Phi table, stage 1 at the start of
     // the xn region (dead once the P waves hold their fragments).
-    constexpr int NF = 2 * KS;
+    constexpr int NF = LOI ? 2 * KS : KS;
     constexpr unsigned WST0 = (unsigned)(XN_BYTES + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES);       // byte offset of stage 0 (stage 1: offset 0)
     auto stage_win = [&](int c) {                      // P waves only
         const f16* p = win_ptr(c);
@@ -351,12 +354,12 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // W_out fragments of chunk c (C waves)
     const int KTO = NCH;
     const long wout_lo = (long)NBC * KTO * 512;
-    half8 woh2[2][NBC], wol2[2][NBC];
+    half8 woh2[2][NBC]; [[maybe_unused]] half8 wol2[2][NBC];
     auto load_wout = [&](int c, int set) {
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb) {
             woh2[set][nb] = *(const half8*)(Wout + (((long)nb * KTO + c) * 64 + lane) * 8);
-            wol2[set][nb] = *(const half8*)(Wout + wout_lo + (((long)nb * KTO + c) * 64 + lane) * 8);
+            if (LOO) wol2[set][nb] = *(const half8*)(Wout + wout_lo + (((long)nb * KTO + c) * 64 + lane) * 8);
         }
     };
     // (the two barrier-separated halves of "(3) done" sit in the role branches below)
@@ -367,7 +370,6 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // MFMAs), then issue this slot's MFMAs with the tap's 16 FMAs dealt between them (a wave's VALU issues in the shadow of its
     // own MFMAs: tools/mb/mb_valu.hip, 1 MFMA + 6 FMAs = 38 cycles).  P: 36 MFMAs per chunk = 9 slots x 4 (C = 48: x 2);
     // C: 12 MFMAs = slots 0-5 x 2.
-    constexpr int KPS = KS / 3;           // project_in k-steps per slot
     int pq[3]; bool pin[3];
 #pragma unroll
     for (int gi = 0; gi < 3; ++gi) {
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         };
         lds_barrier();      // every P wave holds its fragments: the start of the xn region becomes weight stage 1
         f32x16 accp[3];
-        constexpr int NMS = 2 * KPS;               // MFMAs per slot (4 at C = 96, 2 at C = 48)
+        constexpr int NMS = NF / 3;                // MFMAs per slot (two planes: 4 at C = 96, 2 at C = 48; one plane: 2 / 1)
         auto interval = [&](auto PRc, auto UNc, auto PARc, int i) {
             constexpr bool pr = decltype(PRc)::value, un = decltype(UNc)::value && DBG != 2 && DBG != 12 && DBG != 13 && DBG != 14 && DBG != 15 && DBG != 16;
             if (pr && i + 1 < NCH) stage_win(i + 1);                   // chunk i + 1 -> stage (i + 1) & 1, last read in interval i - 1
@@ -511,10 +513,11 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;       // the unit reads chunk i-1's buffer
             const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
             if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
-            // MFMA q of the interval (q = 0 .. 3 NF - 1): fragment ms = q / 3 = (k-step ms >> 1, plane ms & 1: hi, then lo), group q % 3.
+            // MFMA q of the interval (q = 0 .. 3 NF - 1): fragment ms = q / 3 = (k-step ms >> 1, plane ms & 1: hi, then lo; one plane: k-step ms),
+            // group q % 3.
             // fr[ms] is requested one slot before the slot of its first MFMA.
             half8 fr[NF];
-            auto frag_ptr = [&](int ms) { return (const half8*)(wcur + ((ms & 1) * KS + (ms >> 1)) * 1024); };
+            auto frag_ptr = [&](int ms) { return (const half8*)(wcur + (LOI ? (ms & 1) * KS + (ms >> 1) : ms) * 1024); };
             if (pr) {
 #pragma unroll
                 for (int ms = 0; ms <= (NMS - 1) / 3; ++ms) fr[ms] = *frag_ptr(ms);
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 if (pr) {
 #pragma unroll
                     for (int m = 0; m < NMS; ++m) {
-                        const int q = NMS * t + m, ms = q / 3, gi = q - 3 * ms, ks = ms >> 1;
+                        const int q = NMS * t + m, ms = q / 3, gi = q - 3 * ms, ks = LOI ? ms >> 1 : ms;
                         if (ms == 0) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
@@ -612,8 +615,8 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                       else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(woh2[par][nb], fA, accA[nb], 0, 0, 0); }
             if (un) { unit_fma4(sl, 0, t); unit_fma4(sl, 1, t); }
             IRA_PIN();
-            if (cv) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fB, accB[nb], 0, 0, 0);
-                      else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fA, accA[nb], 0, 0, 0); }
+            if (cv && LOO) { if (t & 1) accB[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fB, accB[nb], 0, 0, 0);
+                             else accA[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wol2[par][nb], fA, accA[nb], 0, 0, 0); }
             if (un) { unit_fma4(sl, 2, t); unit_fma4(sl, 3, t); }
             IRA_PIN();
         };
@@ -700,9 +703,11 @@ extern "C" int ira_debug_ffn2_stamps(unsigned long long* out) {
 #endif
 
 bool ffn2_supported(int C, int Hp) { return (C == 48 || C == 96) && Hp % 32 == 0; }
+// lo-plane masks with an instantiation (bit 0: W_in has a lo plane, bit 1: W_out has one): both everywhere; C = 96 also W_in only and neither
+bool ffn2_lo_supported(int C, int lo) { return lo == 3 || (C == 96 && (lo == 1 || lo == 0)); }
 
-template <int C, int LN, bool BIN, bool CB, bool FOLD>
-static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
+template <int C, int LN, bool BIN, bool CB, bool FOLD, bool LOI = true, bool LOO = true>
+static hipError_t ffn2_launch4(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
                                int T, int H, int W, int Hp, int ldo) {
     constexpr size_t LDS = (size_t)NG * (C / 16) * 1024 + 2 * HP_BYTES + 2 * G_BYTES + TAB_BYTES + (size_t)2 * (C / 16) * 1024;   // + weight stage 0
@@ -710,10 +715,10 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
     const float2* tab = nullptr;
     if (hipError_t e = phi_table(&tab); e != hipSuccess) return e;
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD>, LDS, attr_done); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)k_ffn2<C, LN, BIN, CB, FOLD, 0, LOI, LOO>, LDS, attr_done); e != hipSuccess) return e;
     const long nblk = (long)T * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
 #ifdef IRA_KERNEL_DBG
-    if constexpr (C == 96 && LN == 1 && !BIN && !CB && !FOLD) {
+    if constexpr (C == 96 && LN == 1 && !BIN && !CB && !FOLD && LOI && LOO) {
         static const int dbg = getenv("IRA_FFN2_DBG") ? atoi(getenv("IRA_FFN2_DBG")) : 0;
 #define IRA_DBG_LAUNCH(D_)                                                                                                                     \
     if (dbg == D_) {                                                                                                                            \
@@ -727,18 +732,31 @@ static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const 
 #undef IRA_DBG_LAUNCH
     }
 #endif
-    hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
+    hipLaunchKernelGGL((k_ffn2<C, LN, BIN, CB, FOLD, 0, LOI, LOO>), dim3((unsigned)nblk), dim3(512), LDS, st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb,
                        Wout, bout, tab, T, H, W, Hp, ldo);
     return hipGetLastError();
+}
+
+template <int C, int LN, bool BIN, bool CB, bool FOLD>
+static hipError_t ffn2_launch3(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
+                               const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
+                               int T, int H, int W, int Hp, int ldo, int lo) {
+#define IRA_F3(LOI_, LOO_) return ffn2_launch4<C, LN, BIN, CB, FOLD, LOI_, LOO_>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo)
+    if constexpr (C == 96) {
+        if (lo == 0) IRA_F3(false, false);
+        if (lo == 1) IRA_F3(true, false);
+    }
+    IRA_F3(true, true);
+#undef IRA_F3
 }
 
 template <int C, int LN, bool FOLD>
 static hipError_t ffn2_launch2(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout, const float* bout,
-                               int T, int H, int W, int Hp, int ldo) {
+                               int T, int H, int W, int Hp, int ldo, int lo) {
     const bool cb = dwb != nullptr && bout != nullptr;
     if ((dwb != nullptr) != (bout != nullptr)) return hipErrorInvalidValue;
-#define IRA_F2(BIN_, CB_) return ffn2_launch3<C, LN, BIN_, CB_, FOLD>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo)
+#define IRA_F2(BIN_, CB_) return ffn2_launch3<C, LN, BIN_, CB_, FOLD>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo, lo)
     if (bin) { if (cb) IRA_F2(true, true); else IRA_F2(true, false); }
     else { if (cb) IRA_F2(false, true); else IRA_F2(false, false); }
 #undef IRA_F2
@@ -747,8 +765,8 @@ static hipError_t ffn2_launch2(hipStream_t st, const float* x, float* xo, const 
 template <int C>
 static hipError_t ffn2_launch1(hipStream_t st, const float* x, float* xo, const f16* v, const f16* M, long m_stride, const float* wob,
                                int ln_mode, const f16* Win, const float* bin, const float* dww, const float* dwb, const f16* Wout,
-                               const float* bout, int T, int H, int W, int Hp, int ldo) {
-#define IRA_F1(LN_, FOLD_) return ffn2_launch2<C, LN_, FOLD_>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo)
+                               const float* bout, int T, int H, int W, int Hp, int ldo, int lo) {
+#define IRA_F1(LN_, FOLD_) return ffn2_launch2<C, LN_, FOLD_>(st, x, xo, v, M, m_stride, wob, Win, bin, dww, dwb, Wout, bout, T, H, W, Hp, ldo, lo)
     if (ln_mode == 1) { if (v) IRA_F1(1, true); else IRA_F1(1, false); }
     else { if (v) IRA_F1(2, true); else IRA_F1(2, false); }
 #undef IRA_F1
@@ -756,12 +774,13 @@ static hipError_t ffn2_launch1(hipStream_t st, const float* x, float* xo, const 
 
 hipError_t launch_ffn2(hipStream_t st, const float* x, float* xo, const void* v, const void* M, long m_tile_stride, const float* wo_b,
                        int ln_mode, int C, const void* Win, const float* bin, const float* dww, const float* dwb, const void* Wout,
-                       const float* bout, int T, int H, int W, int Hp, int ldo) {
+                       const float* bout, int T, int H, int W, int Hp, int ldo, int lo) {
     if (ldo == 0) ldo = C;
+    if (!ffn2_lo_supported(C, lo)) return hipErrorInvalidValue;
     if (ldo < C || (ldo & 3)) return hipErrorInvalidValue;
     if (x == xo || (ln_mode != 1 && ln_mode != 2) || !ffn2_supported(C, Hp) || ((v != nullptr) != (M != nullptr))) return hipErrorInvalidValue;
-    if (C == 48) return ffn2_launch1<48>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo);
-    return ffn2_launch1<96>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo);
+    if (C == 48) return ffn2_launch1<48>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo, lo);
+    return ffn2_launch1<96>(st, x, xo, (const f16*)v, (const f16*)M, m_tile_stride, wo_b, ln_mode, (const f16*)Win, bin, dww, dwb, (const f16*)Wout, bout, T, H, W, Hp, ldo, lo);
 }
 
 }  // namespace ira

@@ -96,7 +96,10 @@ hipError_t phi_table(const float2** out);
 bool ffn2_supported(int C, int Hp);
 hipError_t launch_ffn2(hipStream_t st, const float* x, float* x_out, const void* v, const void* M, long m_tile_stride, const float* wo_b,
                        int ln_mode, int C, const void* Win, const float* bin, const float* dww, const float* dwb, const void* Wout,
-                       const float* bout, int T, int H, int W, int Hp, int ldo = 0);      // ldo: floats per pixel of x_out (0 = C; a concat buffer's width otherwise)
+                       const float* bout, int T, int H, int W, int Hp, int ldo = 0, int lo = 3);
+// ldo: floats per pixel of x_out (0 = C; a concat buffer's width otherwise).  lo: which 1x1 weights carry a lo plane that is multiplied
+// (bit 0 W_in, bit 1 W_out; ffn2_lo_supported(C, lo): 3 everywhere, 1 and 0 at C = 96): the others are read as plain fp16.
+bool ffn2_lo_supported(int C, int lo);
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const void* W, const float* bias,
                           const float* skip, float* out, int mode, int T, int H, int Wd, int K, int N, int NB, float slope = 0.f,

@@ -25,6 +25,7 @@ struct Blk {   // one TransformerBlock (restormer_arch.py:137-150), device point
     const float* dw2_w = nullptr; const float* dw2_b = nullptr;
     const float* dw2_u = nullptr; const float* dw2_ub = nullptr;   // the same weights per vector-work unit (ira_ffn2.hip; pack.py::_dw_unit_pack)
     const void* pout_w = nullptr; const float* pout_b = nullptr;
+    int ffn_lo1 = 3;   // lo planes the fused GDFN multiplies under weight_planes == 1 (bit 0 project_in, bit 1 project_out; ira_rt_restormer.hip::ffn_lo_rule)
     // X-Restormer only (xrestormer_arch.py:239-262): OCAB and the second GDFN; level = index into spatial_heads
     int level = 0;
     const void* oc_qkv_w = nullptr; const float* oc_qkv_b = nullptr; const float* oc_rel = nullptr;

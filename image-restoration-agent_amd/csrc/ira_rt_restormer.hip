@@ -74,6 +74,18 @@ static bool load_stage(ira_model* m, const char* name, int n, int C, int heads, 
     return true;
 }
 
+// Which lo planes of the fused GDFN's two 1x1s survive weight_planes == 1, by stage (tools/ablate_lo_restormer.py, 27 parity cases, worst
+// |dPSNR| against the 1e-3 dB bar: 5.68e-4 with every GDFN lo plane kept, 5.54e-4 with this rule; profiles/r03_restormer_lo_plane_ablation.txt):
+// decoder level 1 and the refinement stage run both as plain fp16, level 2 keeps project_in's lo plane (dropping it there: 7.2e-4 / 9.2e-4),
+// encoder level 1 keeps both (project_in 9.7e-4, project_out 1.15e-3: rejected).  Only where k_ffn2 has the instantiation (C = 96), only in
+// the Restormer proper (the X-Restormer's blocks were not part of the ablation).
+static int ffn_lo_rule(const ira_model* m, int stage, int C, int Hp) {
+    if (m->xr || C != 96 || !ira::ffn2_supported(C, Hp)) return 3;
+    if (stage == 6 || stage == 7) return 0;              // decoder_level1, refinement
+    if (stage == 1 || stage == 5) return 1;              // encoder_level2, decoder_level2: project_out alone
+    return 3;
+}
+
 bool restormer_bind_weights(ira_model* m) {
     const ira_restormer_config& c = m->cfg;
     const Geo g = make_geo(c, 8, 8);
@@ -90,6 +102,12 @@ bool restormer_bind_weights(ira_model* m) {
     // decoder_level1 / refinement run at dim*2 channels with heads[0] (restormer_arch.py:232-234)
     if (!load_stage(m, "decoder_level1", c.num_blocks[0], g.C[1], g.heads[0], g.Hp[1], 0, m->dec1)) return false;
     if (!load_stage(m, "refinement", c.num_refinement_blocks, g.C[1], g.heads[0], g.Hp[1], 0, m->refine)) return false;
+    {
+        std::vector<Blk>* stages[8] = {&m->enc1, &m->enc2, &m->enc3, &m->lat, &m->dec3, &m->dec2, &m->dec1, &m->refine};
+        const int lv[8] = {0, 1, 2, 3, 2, 1, 1, 1};        // index into g.C / g.Hp (decoder level 1 and refinement: 2 * dim)
+        for (int si = 0; si < 8; ++si)
+            for (Blk& b : *stages[si]) b.ffn_lo1 = ffn_lo_rule(m, si, g.C[lv[si]], g.Hp[lv[si]]);
+    }
     auto c3 = [&](const char* n, int K, int N) { return wptr(m, n, true, (size_t)2 * 9 * up32(N) * K * 2); };
     m->down12 = c3("down1_2_w", g.C[0], g.C[0] / 2);
     m->down23 = c3("down2_3_w", g.C[1], g.C[1] / 2);
@@ -177,9 +195,13 @@ void restormer_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& ou
         const int C = (si >= 6) ? (c.dim << 1) : (c.dim << l);        // decoder level 1 and the refinement stage run at 2 * dim
         const size_t Hp = up32((si >= 6) ? c.hidden[1] : c.hidden[l]), NBq = up32(3 * C), NBc = up32(C);
         if (!hi_plane_level(C)) {
-            // levels of the fused kernels (r3): the qkv 1x1 alone (k_qkv3 skips its lo plane; project_in / project_out keep theirs: their lo
-            // planes cost 4-5e-4 dB of the 1e-3 bar, tools/ablate_lo_restormer.py)
-            if (ira::qkv3_supported(C)) for (Blk& b : *stages[si]) add(b.qkv_w, 2 * NBq * C * 2);
+            // levels of the fused kernels (r3): the qkv 1x1 (k_qkv3 skips its lo plane) and the GDFN 1x1s the stage rule names (ffn_lo_rule:
+            // everywhere else project_in / project_out keep theirs: dropped wholesale they cost 4-5e-4 dB of the 1e-3 bar)
+            for (Blk& b : *stages[si]) {
+                if (ira::qkv3_supported(C)) add(b.qkv_w, 2 * NBq * C * 2);
+                if (!(b.ffn_lo1 & 1)) add(b.pin_w, (size_t)2 * 2 * Hp * C * 2);
+                if (!(b.ffn_lo1 & 2)) add(b.pout_w, 2 * NBc * Hp * 2);
+            }
             continue;
         }
         for (Blk& b : *stages[si]) {
@@ -204,7 +226,7 @@ static bool ffn2_usable(const ira_model* m, const float* dw_u, const float* dw_u
 
 static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const float* dw_w, const float* dw_b, const float* dw_u,
                    const float* dw_ub, const void* pout_w, const float* pout_b, float*& x, float*& alt, int T, int H, int W, int C, int Hp,
-                   const void* v = nullptr, const void* M = nullptr, long m_stride = 0, const float* wo_b = nullptr) {
+                   const void* v = nullptr, const void* M = nullptr, long m_stride = 0, const float* wo_b = nullptr, int lo = 3) {
     const int P = H * W, NBc = up32(C) / 32;
     const int ln = m->cfg.ln_with_bias ? 2 : 1;
     hipStream_t st = m->st;
@@ -222,7 +244,7 @@ static int run_ffn(ira_model* m, const void* pin_w, const float* pin_b, const fl
         // straight into the skip half of decoder level 1's concat buffer.  One shot: cleared here.)
         float* dst = m->ffn_out ? m->ffn_out : alt;
         const int ldo = m->ffn_out ? m->ffn_out_ld : 0;
-        RUN(m, kf, ira::launch_ffn2(st, x, dst, v, M, m_stride, wo_b, ln, C, pin_w, pin_b, dw_u, dw_b ? dw_ub : nullptr, pout_w, pout_b, T, H, W, Hp, ldo));
+        RUN(m, kf, ira::launch_ffn2(st, x, dst, v, M, m_stride, wo_b, ln, C, pin_w, pin_b, dw_u, dw_b ? dw_ub : nullptr, pout_w, pout_b, T, H, W, Hp, ldo, lo));
         if (m->ffn_out) { x = dst; m->ffn_out = nullptr; }
         else std::swap(x, alt);
         return IRA_OK;
@@ -337,7 +359,7 @@ static int run_block(ira_model* m, const Blk& b, float*& x, float*& alt, int T, 
         if ((rc = strip_halo(m, x, H, W, C, lv)) != IRA_OK) return rc;
     }
     rc = run_ffn(m, b.pin_w, b.pin_b, b.dw2_w, b.dw2_b, b.dw2_u, b.dw2_ub, b.pout_w, b.pout_b, x, alt, T, H, W, C, Hp,
-                 fold ? m->v : nullptr, fold ? m->M : nullptr, m_stride, b.wo_b);
+                 fold ? m->v : nullptr, fold ? m->M : nullptr, m_stride, b.wo_b, m->w_planes == 1 ? b.ffn_lo1 : 3);
     if (rc != IRA_OK || !m->xr) return rc;
     // X-Restormer (xrestormer_arch.py:260-261): x += OCAB(norm3(x)); x += spatial_ffn(norm4(x))
     const int sheads = m->xr_spatial_heads[b.level], inner = 16 * sheads, NBo = up32(3 * inner) / 32;

@@ -985,6 +985,14 @@ int ira_op_ffn2(ira_model_t* m, const float* x, float* xo, const void* v, const 
     OP_BODY(m, "op", ira::launch_ffn2(m->st, x, xo, v, M, m_tile_stride, wo_b, ln_mode, C, Win, bin, dwu, dwub, Wout, bout, T, H, W, Hp));
 }
 
+int ira_op_ffn2_planes(ira_model_t* m, int lo_mask, const float* x, float* xo, const void* v, const void* M, long m_tile_stride, const float* wo_b,
+                       int ln_mode, int C, const void* Win, const float* bin, const float* dwu, const float* dwub, const void* Wout,
+                       const float* bout, int T, int H, int W, int Hp) {
+    if (!m) return IRA_ERR_ARG;
+    if (!ira::ffn2_lo_supported(C, lo_mask)) return m->fail(IRA_ERR_ARG, "ira_op_ffn2_planes: no kernel for lo_mask %d at C = %d (3 everywhere; 0 and 1 at C = 96)", lo_mask, C);
+    OP_BODY(m, "op", ira::launch_ffn2(m->st, x, xo, v, M, m_tile_stride, wo_b, ln_mode, C, Win, bin, dwu, dwub, Wout, bout, T, H, W, Hp, 0, lo_mask));
+}
+
 // planes 1: the lo planes of the layers that have a hi-plane kernel are saved to a device-side copy and zeroed in the handle's blob, so that
 // launches too small for the hi-plane kernels (which then run the two-plane ones) still give the same numbers; planes 2 copies them back.
 static int set_weight_planes_locked(ira_model_t* m, int planes) {

@@ -126,6 +126,7 @@ SIGNATURES = {
     'ira_op_conv3x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     'ira_op_ffn_fused': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     'ira_op_ffn2': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    'ira_op_ffn2_planes': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     'ira_set_ffn_generation': (_i, [_vp, _i]),
     'ira_set_weight_planes': (_i, [_vp, _i]),
     'ira_get_weight_planes': (_i, [_vp, _vp]),

@@ -112,11 +112,13 @@ def pack_block(sd, p: str, dim: int, hid: int, cfg: RestormerConfig, out: dict, 
 
     # IRA_ABLATE_LO_L12 (accuracy ablation, tools/ablate_lo_restormer.py): comma list of {qkv, pin, pout}: the lo planes of those 1x1 weights are
     # zeroed on the levels the fused kernels run (dim in {48, 96}) - numerically what a kernel that skips the lo-plane MFMAs computes
+    # entries are a layer kind or kind@stage (stage = the state-dict prefix of the block's stage, e.g. pin@decoder_level1)
     abl = set(filter(None, os.environ.get('IRA_ABLATE_LO_L12', '').split(','))) if dim in (48, 96) else set()
+    stage = p.split('.')[0]
 
     def planes(a, kind):
         sp = split16(a)
-        if kind in abl:
+        if kind in abl or f'{kind}@{stage}' in abl:
             sp[1] = 0
         return frag_major(sp)
 

@@ -391,6 +391,13 @@ int ira_op_ffn_fused(ira_model_t* m, const float* x_dev, float* x_out_dev, int l
 int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void* v_dev, const void* M_dev, long m_tile_stride,
                 const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev, const float* dwu_dev,
                 const float* dwub_dev, const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
+/* The same with a choice of which 1x1 weights are multiplied as fp16 hi + lo planes (lo_mask bit 0: project_in, bit 1: project_out; 3 =
+ * ira_op_ffn2) and which as plain fp16 (their lo plane is not read).  Kernels exist for 3 at C in {48, 96} and for 0 and 1 at C = 96 - the
+ * forms the Restormer schedule uses under weight_planes == 1 (decoder level 1 / refinement: 0; level 2: 1); anything else is
+ * IRA_ERR_ARG.  On weights whose lo plane is zero the plain form gives the two-plane form's result bit for bit. */
+int ira_op_ffn2_planes(ira_model_t* m, int lo_mask, const float* x_dev, float* x_out_dev, const void* v_dev, const void* M_dev,
+                       long m_tile_stride, const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev,
+                       const float* dwu_dev, const float* dwub_dev, const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
 
 /* Which fused GDFN kernel the Restormer schedule uses: 2 (default) = ira_op_ffn2 with the attention apply folded in, 1 = ira_op_ffn_fused
  * after a separate apply kernel.  For A/B measurements; also settable with the environment variable IRA_FFN_GEN at create time. */

@@ -614,6 +614,66 @@ def test_ffn2_matches_generation_1(ctx):
     assert dlt <= 5e-4 * br + 1e-6
 
 
+@pytest.mark.parametrize('lo_mask', [0, 1])
+@pytest.mark.parametrize('ln,bias,fold,T,H,W', [(1, False, True, 2, 24, 64), (2, True, True, 1, 19, 45), (1, False, False, 1, 16, 96), (2, True, False, 2, 8, 32)])
+def test_ffn2_plain_fp16_forms(ctx, lo_mask, ln, bias, fold, T, H, W):
+    """The plain-fp16 forms of k_ffn2 (lo_mask 0: neither 1x1 has a lo plane, 1: project_in alone has one; what the schedule runs at decoder
+    level 1 / refinement and at level 2 under weight_planes == 1): on weights whose dropped lo planes are ZERO - the state of the handle's
+    blob - they must give the two-plane kernel's output bit for bit (a tile's result may not depend on which form ran), and they never
+    read the dropped plane (poisoned here with NaN)."""
+    from ira_amd.config import RestormerConfig
+    from ira_amd.pack import pack_block
+    C, hid = 96, 255
+    g = torch.Generator().manual_seed(31 * lo_mask + ln + H)
+    Hp = up32(hid)
+    x = torch.randn(T, H, W, C, generator=g) * 1.5
+    sd = _ffn_block_sd(C, hid, ln, bias, g)
+    cfg = RestormerConfig(dim=C, LayerNorm_type='BiasFree' if ln == 1 else 'WithBias', bias=bias)
+    cfg.hidden = lambda d: hid
+    arrs = {}
+    pack_block(sd, 'b', C, hid, cfg, arrs, 'b')
+    NBc = up32(C) // 32
+    vd = Md = wob = None
+    if fold:
+        Mp = torch.zeros(T, NBc * 32, C)
+        Mp[:, :C] = torch.randn(T, C, C, generator=g) / C ** 0.5
+        Md = dev(split16(Mp).permute(1, 0, 2, 3, 4, 5))
+        vd = dev(torch.randn(T, H, W, C, generator=g).half())
+        if bias:
+            wob = dev(torch.from_numpy(arrs['b.wo_b']))
+
+    def planes(name, lo_value):
+        w = torch.from_numpy(np.ascontiguousarray(arrs[name])).clone().view(torch.int16).reshape(-1)
+        assert w.numel() % 2 == 0
+        if lo_value is not None:
+            w[w.numel() // 2:] = lo_value                 # the lo plane is the second half of the packed array (pack.py::split16 layout)
+        return dev(w)
+    drop_in, drop_out = not (lo_mask & 1), not (lo_mask & 2)
+    NAN16 = 0x7e00
+    d = {k: dev(torch.from_numpy(np.ascontiguousarray(v_))) for k, v_ in arrs.items()}
+    win0, wout0 = planes('b.pin_w', 0 if drop_in else None), planes('b.pout_w', 0 if drop_out else None)
+    winN, woutN = planes('b.pin_w', NAN16 if drop_in else None), planes('b.pout_w', NAN16 if drop_out else None)
+    xd = dev(x)
+    o2 = torch.full(x.shape, float('nan')).cuda(); o1 = torch.full(x.shape, float('nan')).cuda()
+    tail = (ptr(d.get('b.pin_b')), ptr(d['b.dw2_u']), ptr(d.get('b.dw2_ub')))
+    rc = ctx._lib.ira_op_ffn2(ctx.handle, ptr(xd), ptr(o2), ptr(vd), ptr(Md), 2 * NBc * 32 * C, ptr(wob), ln, C, ptr(win0), *tail, ptr(wout0),
+                              ptr(d.get('b.pout_b')), T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    rc = ctx._lib.ira_op_ffn2_planes(ctx.handle, lo_mask, ptr(xd), ptr(o1), ptr(vd), ptr(Md), 2 * NBc * 32 * C, ptr(wob), ln, C, ptr(winN), *tail,
+                                     ptr(woutN), ptr(d.get('b.pout_b')), T, H, W, Hp)
+    assert rc == 0, ctx._lib.ira_last_error(ctx.handle)
+    assert torch.isfinite(o1).all(), "the plain-fp16 form read a lo plane it should not"
+    assert torch.equal(o1, o2), f"{int((o1 != o2).sum())} outputs differ, max {float((o1 - o2).abs().max()):.3e}"
+
+
+def test_ffn2_plain_fp16_forms_only_where_built(ctx):
+    """lo masks without an instantiation are an argument error, not a silent two-plane run."""
+    z = torch.zeros(4096, device='cuda')
+    for C, mask in [(48, 0), (48, 1), (96, 2), (96, 5)]:
+        rc = ctx._lib.ira_op_ffn2_planes(ctx.handle, mask, ptr(z), ptr(z), None, None, 0, None, 1, C, ptr(z), None, ptr(z), None, ptr(z), None, 1, 8, 32, 32)
+        assert rc != 0 and 'lo_mask' in ctx._lib.ira_last_error(ctx.handle).decode()
+
+
 @pytest.mark.parametrize('C,ln,T,H,W,bias', [
     (48, 1, 2, 11, 40, False),      # ragged patch edges; W % 8 == 0
     (96, 1, 1, 16, 64, False),

@@ -58,7 +58,11 @@ if os.environ.get('IRA_FFN2_DBG'):
         print('P slot stamps (interval 5: before wait, after wait, ...):', [int(v_ - t0) for v_ in P_[32:] if v_])
         print('C slot stamps:', [int(v_ - t0) for v_ in C_[32:] if v_])
     sys.exit(0)
-fns = [('gen1 apply+ffn_fused', gen1), ('gen1 ffn_fused only', gen1_ffn_only), ('gen2 ffn2 with fold', gen2), ('gen2 ffn2 no fold', gen2_nofold)]
+def gen2_lo(mask):
+    def f():
+        assert L.ira_op_ffn2_planes(be.handle, mask, p(x), p(out), p(v), p(Md), stride, None, 1, Cc, p(d['b.pin_w']), None, p(d['b.dw2_u']), None, p(d['b.pout_w']), None, T, H, W, Hp) == 0
+    return f
+fns = [('gen1 apply+ffn_fused', gen1), ('gen1 ffn_fused only', gen1_ffn_only), ('gen2 ffn2 with fold', gen2), ('gen2 ffn2 no fold', gen2_nofold)] + ([('gen2 fold, W_out plain fp16', gen2_lo(1)), ('gen2 fold, both plain fp16', gen2_lo(0))] if Cc == 96 else [])
 for _, f in fns: f()
 torch.cuda.synchronize()
 o1 = None
