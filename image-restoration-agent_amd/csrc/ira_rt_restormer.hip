@@ -1,6 +1,8 @@
 // Restormer (restormer_arch.py:193-284): weight binding, workspace, forward schedule of libira_hip.so's runtime.
 #include "ira_model.h"
 
+#include <cstring>
+
 namespace ira_rt {
 
 struct Geo {   // per-level geometry for a batch of T tiles of H x W
@@ -74,15 +76,21 @@ static bool load_stage(ira_model* m, const char* name, int n, int C, int heads, 
     return true;
 }
 
-// Which lo planes of the fused GDFN's two 1x1s survive weight_planes == 1, by stage (tools/ablate_lo_restormer.py, 27 parity cases, worst
-// |dPSNR| against the 1e-3 dB bar: 5.68e-4 with every GDFN lo plane kept, 5.54e-4 with this rule; profiles/r03_restormer_lo_plane_ablation.txt):
-// decoder level 1 and the refinement stage run both as plain fp16, level 2 keeps project_in's lo plane (dropping it there: 7.2e-4 / 9.2e-4),
-// encoder level 1 keeps both (project_in 9.7e-4, project_out 1.15e-3: rejected).  Only where k_ffn2 has the instantiation (C = 96), only in
-// the Restormer proper (the X-Restormer's blocks were not part of the ablation).
+// Which lo planes of the fused GDFN's two 1x1s are multiplied under weight_planes == 1, by stage: ALL of them (mask 3) unless
+// IRA_FFN_LO_STAGES says otherwise.  k_ffn2 has one-plane forms at C = 96 (masks 0 and 1), 7.93 -> 7.08 ms per 40-tile level-1 launch, and the
+// stage-wise GPU ablation over the 27 golden cases found a rule that cost nothing there (decoder level 1 + refinement mask 0, level 2 mask 1:
+// worst |dPSNR| 5.54e-4 against 5.68e-4; frame 206 -> 202 ms) - but on eleven cases with weights, tasks and image sizes no golden was made from
+// (tools/ablate_lo_restormer.py, ABLATE_UNSEEN=1) the same rule reaches 1.24e-3 dB on a 72 x 88 image where keeping every plane stays at
+// 6.7e-4, and every narrower rule tried lands between 7.7e-4 and 1.0e-3 (profiles/r03_restormer_lo_plane_ablation.txt).  The bar is 1e-3: the
+// rule is NOT the default.  The switch stays for A/B runs: eight digits, the mask of stage 0..7 (encoder levels 1-3, latent, decoder levels
+// 3-1, refinement), read when a handle binds its weights; the handle zeroes exactly the lo planes the masks drop, so the unfused path and
+// generation 1 give the same numbers as the one-plane kernels.
 static int ffn_lo_rule(const ira_model* m, int stage, int C, int Hp) {
     if (m->xr || C != 96 || !ira::ffn2_supported(C, Hp)) return 3;
-    if (stage == 6 || stage == 7) return 0;              // decoder_level1, refinement
-    if (stage == 1 || stage == 5) return 1;              // encoder_level2, decoder_level2: project_out alone
+    if (const char* e = getenv("IRA_FFN_LO_STAGES"); e && strlen(e) == 8) {
+        const int v = e[stage] - '0';
+        if (ira::ffn2_lo_supported(C, v)) return v;
+    }
     return 3;
 }
 
@@ -195,8 +203,8 @@ void restormer_lo_planes(ira_model* m, std::vector<std::pair<void*, size_t>>& ou
         const int C = (si >= 6) ? (c.dim << 1) : (c.dim << l);        // decoder level 1 and the refinement stage run at 2 * dim
         const size_t Hp = up32((si >= 6) ? c.hidden[1] : c.hidden[l]), NBq = up32(3 * C), NBc = up32(C);
         if (!hi_plane_level(C)) {
-            // levels of the fused kernels (r3): the qkv 1x1 (k_qkv3 skips its lo plane) and the GDFN 1x1s the stage rule names (ffn_lo_rule:
-            // everywhere else project_in / project_out keep theirs: dropped wholesale they cost 4-5e-4 dB of the 1e-3 bar)
+            // levels of the fused kernels (r3): the qkv 1x1 (k_qkv3 skips its lo plane); project_in / project_out keep theirs (dropped they
+            // cost 4-5e-4 dB of the 1e-3 bar) unless an A/B run names stages with IRA_FFN_LO_STAGES (ffn_lo_rule)
             for (Blk& b : *stages[si]) {
                 if (ira::qkv3_supported(C)) add(b.qkv_w, 2 * NBq * C * 2);
                 if (!(b.ffn_lo1 & 1)) add(b.pin_w, (size_t)2 * 2 * Hp * C * 2);

@@ -392,9 +392,10 @@ int ira_op_ffn2(ira_model_t* m, const float* x_dev, float* x_out_dev, const void
                 const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev, const float* dwu_dev,
                 const float* dwub_dev, const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);
 /* The same with a choice of which 1x1 weights are multiplied as fp16 hi + lo planes (lo_mask bit 0: project_in, bit 1: project_out; 3 =
- * ira_op_ffn2) and which as plain fp16 (their lo plane is not read).  Kernels exist for 3 at C in {48, 96} and for 0 and 1 at C = 96 - the
- * forms the Restormer schedule uses under weight_planes == 1 (decoder level 1 / refinement: 0; level 2: 1); anything else is
- * IRA_ERR_ARG.  On weights whose lo plane is zero the plain form gives the two-plane form's result bit for bit. */
+ * ira_op_ffn2) and which as plain fp16 (their lo plane is not read).  Kernels exist for 3 at C in {48, 96} and for 0 and 1 at C = 96;
+ * anything else is IRA_ERR_ARG.  On weights whose lo plane is zero the plain form gives the two-plane form's result bit for bit.  The network
+ * schedule runs mask 3 everywhere (the one-plane forms measured 11 % faster but cost parity margin: DESIGN.md 4); the environment variable
+ * IRA_FFN_LO_STAGES (eight digits, one mask per Restormer stage, read at create time) selects them for A/B runs. */
 int ira_op_ffn2_planes(ira_model_t* m, int lo_mask, const float* x_dev, float* x_out_dev, const void* v_dev, const void* M_dev,
                        long m_tile_stride, const float* wo_b_dev, int ln_mode, int C, const void* Win_dev, const float* bin_dev,
                        const float* dwu_dev, const float* dwub_dev, const void* Wout_dev, const float* bout_dev, int T, int H, int W, int Hp);

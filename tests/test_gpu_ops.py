@@ -617,9 +617,9 @@ def test_ffn2_matches_generation_1(ctx):
 @pytest.mark.parametrize('lo_mask', [0, 1])
 @pytest.mark.parametrize('ln,bias,fold,T,H,W', [(1, False, True, 2, 24, 64), (2, True, True, 1, 19, 45), (1, False, False, 1, 16, 96), (2, True, False, 2, 8, 32)])
 def test_ffn2_plain_fp16_forms(ctx, lo_mask, ln, bias, fold, T, H, W):
-    """The plain-fp16 forms of k_ffn2 (lo_mask 0: neither 1x1 has a lo plane, 1: project_in alone has one; what the schedule runs at decoder
-    level 1 / refinement and at level 2 under weight_planes == 1): on weights whose dropped lo planes are ZERO - the state of the handle's
-    blob - they must give the two-plane kernel's output bit for bit (a tile's result may not depend on which form ran), and they never
+    """The plain-fp16 forms of k_ffn2 (lo_mask 0: neither 1x1 has a lo plane, 1: project_in alone has one; the schedule runs them only
+    under the A/B switch IRA_FFN_LO_STAGES): on weights whose dropped lo planes are ZERO - what the handle makes of its blob
+    then - they must give the two-plane kernel's output bit for bit (a tile's result may not depend on which form ran), and they never
     read the dropped plane (poisoned here with NaN)."""
     from ira_amd.config import RestormerConfig
     from ira_amd.pack import pack_block

@@ -24,9 +24,32 @@ refB = []
 for (y0, x0) in tiles:
     refB.append(O.restore_image(noisy[y0:y0 + 512, x0:x0 + 512], to_torch(sdB), cfgB.to_dict()))
     print('oracle tile', y0, x0, 'done', flush=True)
-for st in sets:
+# cases on weights and images no golden was made from (ABLATE_UNSEEN=1): the agent-API tests' three, and eight more tasks / seeds / sizes
+unseen = []
+if os.environ.get('ABLATE_UNSEEN'):
+    specs = [('Motion_Deblurring', 7, 72, 88, 3, 11, None, 32), ('Real_Denoising', 7, 64, 80, 3, 12, 48, 16), ('Gaussian_Gray_Denoising', 7, 56, 56, 1, 13, None, 32),
+             ('Motion_Deblurring', 3, 96, 120, 3, 31, None, 32), ('Deraining', 5, 80, 112, 3, 32, None, 32), ('Real_Denoising', 9, 128, 128, 3, 33, None, 32),
+             ('Single_Image_Defocus_Deblurring', 4, 72, 104, 3, 34, None, 32), ('Gaussian_Color_Denoising', 6, 88, 88, 3, 35, None, 32),
+             ('Real_Denoising', 2, 160, 160, 3, 36, 96, 32), ('Motion_Deblurring', 8, 64, 64, 3, 37, None, 32), ('Deraining', 1, 120, 88, 3, 38, 64, 16)]
+    for (task, wseed, hh, ww, ch, iseed, tile, ov) in specs:
+        cfgU = task_config(task); sdU = seeded_state_dict(cfgU, wseed)
+        cl, nz = O.synthetic_noisy_image(hh, ww, ch, seed=iseed)
+        rf = O.restore_image(nz, to_torch(sdU), cfgU.to_dict(), tile=tile, tile_overlap=ov)
+        unseen.append((f'unseen {task} w{wseed} {hh}x{ww}', cfgU, sdU, cl, nz, rf, tile, ov))
+        print('oracle', unseen[-1][0], 'done', flush=True)
+rules = [r for r in os.environ.get('ABLATE_RULES', '').split(',') if r] or [None]
+if len(rules) > 1 or rules[0]: sets = [(st, r) for st in sets[:1] for r in rules]
+else: sets = [(st, None) for st in sets]
+for st, rule in sets:
     os.environ['IRA_ABLATE_LO_L12'] = st
+    if rule: os.environ['IRA_FFN_LO_STAGES'] = rule
     worst = 0.0; rows = []
+    for (name, cfgU, sdU, cl, nz, rf, tile, ov) in unseen:
+        with RestormerBackend(cfgU, sdU, device=0) as be:
+            out = be.restore(nz, tile=tile, tile_overlap=ov)
+        d = O.psnr_u8(out, cl) - O.psnr_u8(rf, cl)
+        rows.append((name, d, int(np.abs(out.astype(int) - rf.astype(int)).max())))
+        worst = max(worst, abs(d))
     for f in files:
         z = np.load(f, allow_pickle=False)
         cfg = RestormerConfig(**json.loads(str(z['cfg'])))
@@ -47,4 +70,6 @@ for st in sets:
             d = O.psnr_u8(out, cl) - O.psnr_u8(rf, cl)
             rows.append((f'bench tile {y0},{x0}', d, int(np.abs(out.astype(int) - rf.astype(int)).max())))
             worst = max(worst, abs(d))
+    if rule: st = f'{st} rule {rule}'
+    if unseen: print('   unseen cases:', [(n, f'{d:+.2e}') for (n, d, _) in rows[:len(unseen)]], flush=True)
     print(f"ablate [{st}]: worst |dPSNR| {worst:.2e} dB over {len(rows)} cases; the five worst:", sorted(rows, key=lambda r: -abs(r[1]))[:5], flush=True)
