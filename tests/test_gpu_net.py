@@ -180,6 +180,30 @@ def test_benchmark_size_properties():
     assert p >= 58.0 and abs(d) <= 1e-3
 
 
+@pytest.mark.parametrize('task,wseed,H,W,ch,iseed,tile,overlap', [
+    ('Motion_Deblurring', 3, 96, 120, 3, 31, None, 32), ('Deraining', 5, 80, 112, 3, 32, None, 32), ('Real_Denoising', 9, 128, 128, 3, 33, None, 32),
+    ('Single_Image_Defocus_Deblurring', 4, 72, 104, 3, 34, None, 32), ('Gaussian_Color_Denoising', 6, 88, 88, 3, 35, None, 32),
+    ('Real_Denoising', 2, 160, 160, 3, 36, 96, 32), ('Motion_Deblurring', 8, 64, 64, 3, 37, None, 32), ('Deraining', 1, 120, 88, 3, 38, 64, 16),
+])
+def test_unseen_tasks_seeds_sizes(task, wseed, H, W, ch, iseed, tile, overlap):
+    """Cases no golden fixture and no tuning run was made from (r3): five task configurations, other weight seeds, small odd sizes, tiled and
+    whole, through the u8 harness against the CPU oracle.  On images this small dPSNR is a noisy statistic - the default numerics sit at
+    <= 6.7e-4 dB here, and a weight-plane rule fitted to the 27 golden cases (IRA_FFN_LO_STAGES) broke the 1e-3 bar on this
+    kind of case, which is why they are in the suite."""
+    from ira_amd.backend import RestormerBackend
+    cfg = task_config(task)
+    sd = seeded_state_dict(cfg, wseed)
+    clean, noisy = O.synthetic_noisy_image(H, W, ch, seed=iseed)
+    torch.set_num_threads(16)
+    ref = O.restore_image(noisy, to_torch(sd), cfg.to_dict(), tile=tile, tile_overlap=overlap)
+    with RestormerBackend(cfg, sd, device=0) as be:
+        out = be.restore(noisy, tile=tile, tile_overlap=overlap)
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    d = O.psnr_u8(out, clean) - O.psnr_u8(ref, clean)
+    print(f"{task} w{wseed} {H}x{W}: u8 mismatch {(diff > 0).mean():.4f}, max {diff.max()}, dPSNR {d:+.2e} dB")
+    assert diff.max() <= 2 and abs(d) <= 1e-3, (int(diff.max()), d)
+
+
 @pytest.mark.parametrize('name,cfgf,seed,H,W,planes', [
     ('reduced_p1', lambda: reduced_config('BiasFree'), 41, 72, 88, 1),
     ('full_p1', lambda: task_config('Real_Denoising'), 42, 64, 64, 1),
