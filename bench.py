@@ -778,7 +778,7 @@ def main():
                                    + (f'{world} horizontal band(s) with halo-row and Gram exchange' if whole else f'tile-parallel over {world} GPU(s)'),
                        'frames_per_s': round(value / mp_out, 4), 'tiles': n_tiles,
                        'device_ms_per_step_rank0': round(dev_ms / args.steps, 3),
-                       'weight_planes': f'{be.weight_planes} (1 = the handle default after ira_model_create: plain fp16 weights in the 1x1 layers of the levels with 192 / 384 channels, hi + lo planes elsewhere; DESIGN.md 4)',
+                       'weight_planes': f'{be.weight_planes} (1 = the handle default after ira_model_create: plain fp16 weights in the 1x1 layers of the levels with 192 / 384 channels and in the qkv 1x1 of levels 1-2, fp16 hi + lo planes elsewhere; DESIGN.md 4)',
                        'timed_region': 'frame resident in HBM before the timed region, uint8 result left in HBM; the H2D / D2H copies of the host-buffer entry (24.9 MB each way) are outside it',
                        **({'collective': data_path} if world > 1 else {})},
             'net_roofline': {'bound': 'hbm', 'algorithmic_GB_per_step': round(net_bytes / 1e9, 2),
