@@ -13,6 +13,7 @@ from ira_amd.config import RestormerConfig, task_config
 from ira_amd.weights import seeded_state_dict, to_torch
 from oracle import restormer_oracle as O
 
+PLANES = int(os.environ.get('ABLATE_PLANES', '1'))      # 2: every MFMA weight as fp16 hi + lo (ira_set_weight_planes)
 GOLD = os.path.join(R, 'tests', 'golden')
 files = sorted(glob.glob(os.path.join(GOLD, 'harness_*.npz'))) + sorted(glob.glob(os.path.join(GOLD, 'sweep_*.npz')))
 sets = sys.argv[1:] or ['', 'qkv', 'pin', 'pout', 'qkv,pin', 'qkv,pin,pout']
@@ -45,7 +46,7 @@ for st, rule in sets:
     if rule: os.environ['IRA_FFN_LO_STAGES'] = rule
     worst = 0.0; rows = []
     for (name, cfgU, sdU, cl, nz, rf, tile, ov) in unseen:
-        with RestormerBackend(cfgU, sdU, device=0) as be:
+        with RestormerBackend(cfgU, sdU, device=0, weight_planes=PLANES) as be:
             out = be.restore(nz, tile=tile, tile_overlap=ov)
         d = O.psnr_u8(out, cl) - O.psnr_u8(rf, cl)
         rows.append((name, d, int(np.abs(out.astype(int) - rf.astype(int)).max())))
@@ -56,14 +57,14 @@ for st, rule in sets:
         kw = {}
         if 'residual_scale' in z.files: kw['residual_scale'] = float(z['residual_scale'])
         sd = seeded_state_dict(cfg, int(z['seed']), **kw)
-        with RestormerBackend(cfg, sd, device=0) as be:
+        with RestormerBackend(cfg, sd, device=0, weight_planes=PLANES) as be:
             tile = int(z['tile']) if int(z['tile']) > 0 else None
             out = be.restore(z['noisy'], tile=tile, tile_overlap=int(z['overlap']))
         ref = z['restored']; cl = z['clean']
         d = O.psnr_u8(out, cl) - O.psnr_u8(ref, cl)
         rows.append((os.path.basename(f), d, int(np.abs(out.astype(int) - ref.astype(int)).max())))
         worst = max(worst, abs(d))
-    with RestormerBackend(cfgB, sdB, device=0) as be:
+    with RestormerBackend(cfgB, sdB, device=0, weight_planes=PLANES) as be:
         for (y0, x0), rf in zip(tiles, refB):
             out = be.restore(noisy[y0:y0 + 512, x0:x0 + 512])
             cl = clean[y0:y0 + 512, x0:x0 + 512]
@@ -71,5 +72,6 @@ for st, rule in sets:
             rows.append((f'bench tile {y0},{x0}', d, int(np.abs(out.astype(int) - rf.astype(int)).max())))
             worst = max(worst, abs(d))
     if rule: st = f'{st} rule {rule}'
+    if PLANES != 1: st = f'{st} weight_planes {PLANES}'
     if unseen: print('   unseen cases:', [(n, f'{d:+.2e}') for (n, d, _) in rows[:len(unseen)]], flush=True)
     print(f"ablate [{st}]: worst |dPSNR| {worst:.2e} dB over {len(rows)} cases; the five worst:", sorted(rows, key=lambda r: -abs(r[1]))[:5], flush=True)
