@@ -2,7 +2,11 @@
 measured ON THE GPU through the harness: for each ablation set, |PSNR(build, clean) - PSNR(oracle, clean)| on the reference-generated
 harness goldens, the 18 robustness-sweep goldens and three 512^2 tiles of the benchmark frame (oracle on the CPU).  Zeroing the lo planes
 in the blob (IRA_ABLATE_LO_L12, ira_amd/pack.py) is numerically what a kernel that skips the lo-plane MFMAs computes.
-usage: python tools/ablate_lo_restormer.py [sets ...]   e.g.  '' qkv pin qkv,pin qkv,pin,pout"""
+usage: python tools/ablate_lo_restormer.py [sets ...]   e.g.  '' qkv pin qkv,pin qkv,pin,pout   (tags also as kind@stage, e.g. pin@decoder_level1)
+environment: ABLATE_UNSEEN=1 adds eleven cases on tasks / weight seeds / sizes no golden was made from (oracle on the CPU);
+ABLATE_RULES=r1,r2,... runs the first set under each IRA_FFN_LO_STAGES rule (eight digits, csrc/ira_rt_restormer.hip::ffn_lo_rule);
+ABLATE_PLANES=2 creates the handles with every weight as fp16 hi + lo (the noise floor of the statistic).
+Results of round 3: profiles/r03_restormer_lo_plane_ablation.txt, DESIGN.md 4."""
 import glob, json, os, sys
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(R, 'image-restoration-agent_amd')); sys.path.insert(0, R)
