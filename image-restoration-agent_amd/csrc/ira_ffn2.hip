@@ -393,7 +393,16 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         if (DBG == 5) { uva[slot] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; uvb[slot] = uva[slot]; }
         else { uva[slot] = lds_read128<off0>(hbase); uvb[slot] = lds_read128<off1>(hbase); }
         if (DBG == 1) { for (int e = 0; e < 16; ++e) uw[slot][e] = 0.01f * (e + 1); }
-        else uw[slot] = sload16(wunit + 16 * t);
+        else if (t > 0) uw[slot] = sload16(wunit + 16 * t);
+    };
+    // Slot 0's weights are NOT requested with its hp values at the start of the interval (r3 end): a unit's 576 bytes are nine fresh 64-byte
+    // lines for the scalar cache every interval, an s_load that misses there comes back from L2 in about as long as a whole slot lasts, and
+    // requested right behind the barrier its latency lay open once per interval (diagnostic build with constant weights: 7.22 -> 6.43 ms per
+    // 40-tile launch).  They are requested one interval ahead instead - in slot 8, into the register set slot 7 has just finished with: nine
+    // slots per interval, so the sets swap roles from one interval to the next: slot t of interval i uses set (t + i) & 1.
+    auto unit_w0 = [&](const float* wunit, int set) {
+        if (DBG == 1) { for (int e = 0; e < 16; ++e) uw[set][e] = 0.01f * (e + 1); }
+        else uw[set] = sload16(wunit);
     };
     f32x16 ubias;
     auto unit_init = [&](int c) {
@@ -512,7 +521,8 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             const char* wcur = smem + ((i & 1) ? 0u : WST0) + lane * 16;
             const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;       // the unit reads chunk i-1's buffer
             const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
-            if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
+            constexpr int par = decltype(PARc)::value;                 // = i & 1
+            if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, par); }
             // MFMA q of the interval (q = 0 .. 3 NF - 1): fragment ms = q / 3 = (k-step ms >> 1, plane ms & 1: hi, then lo; one plane: k-step ms),
             // group q % 3.
             // fr[ms] is requested one slot before the slot of its first MFMA.
@@ -523,12 +533,13 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 for (int ms = 0; ms <= (NMS - 1) / 3; ++ms) fr[ms] = *frag_ptr(ms);
             }
             auto slot = [&](auto TC) {
-                constexpr int t = decltype(TC)::value, sl = t & 1;
+                constexpr int t = decltype(TC)::value, sl = (t + par) & 1;
                 SLOTSTAMP(i);
                 IRA_WAIT_LGKM();
                 SLOTSTAMP(i);
                 IRA_PIN();
                 if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
+                if constexpr (t == 8 && DBG != 2 && DBG < 12) { if (i < NCH) unit_w0(dwu + (long)(i * 2 + uoc) * 144, sl ^ 1); }   // the next interval's slot 0
                 if (pr && t < 8) {
 #pragma unroll
                     for (int ms = (NMS * t + NMS - 1) / 3 + 1; ms <= (NMS * (t + 1) + NMS - 1) / 3; ++ms) fr[ms] = *frag_ptr(ms);
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             STAMP();
         };
         using I0 = IC<0>; using I1 = IC<1>;
-        interval(std::true_type{}, std::false_type{}, I0{}, 0);
+        interval(std::true_type{}, std::false_type{}, I0{}, 0);      // (its slot 8 requests chunk 0's first weights for interval 1)
         for (int i = 1; i + 1 < NCH; i += 2) {                          // NCH is even (Hp % 32 == 0): intervals 1 .. NCH-2 in pairs
             interval(std::true_type{}, std::true_type{}, I1{}, i);
             interval(std::true_type{}, std::true_type{}, I0{}, i + 1);
@@ -594,19 +605,21 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         if (un_) load_wout(i - 1, par ^ 1);                            // chunk i - 1 is consumed in the next interval
         const unsigned hbase = hb_lane + (unsigned)((i - 1) & 1) * (unsigned)HP_BYTES;
         const float* wunit = dwu + (long)((i - 1) * 2 + uoc) * 144;
-        if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, 0); }
+        constexpr int upar = par;                                      // i & 1 as well: the unit's register sets, see unit_w0
+        if (un) { unit_init(i - 1); unit_request(hbase, wunit, IC<0>{}, upar); }
         if (co) {
             fA = gbuf[((((i - 2) & 1) * 4 + cw) * 2 + 0) * 64 + lane];
             fB = gbuf[((((i - 2) & 1) * 4 + cw) * 2 + 1) * 64 + lane];
         }
         auto slot = [&](auto TC) {
-            constexpr int t = decltype(TC)::value, sl = t & 1, nb = (t >> 1) < NBC ? (t >> 1) : 0;
+            constexpr int t = decltype(TC)::value, sl = (t + upar) & 1, nb = (t >> 1) < NBC ? (t >> 1) : 0;
             constexpr bool cv = co && (t >> 1) < NBC;
             SLOTSTAMP(i);
             IRA_WAIT_LGKM();
             SLOTSTAMP(i);
             IRA_PIN();
             if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
+            if constexpr (t == 8 && DBG != 2 && DBG < 12) { if (un_ && i < NCH) unit_w0(dwu + (long)(i * 2 + uoc) * 144, sl ^ 1); }
             IRA_PIN();
             if (un && t == 5) unit_gelu_a(0);
             if (un && t == 6) { unit_gelu_b(0); unit_gelu_a(4); }
@@ -626,6 +639,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         if (un_) lds_barrier();
         STAMP();
     };
+    unit_w0(dwu + (long)uoc * 144, 1);                      // chunk 0's unit runs in interval 1: set (0 + 1) & 1
     lds_barrier();                                          // the barrier of interval 0 (P only)
     STAMP();
     {
