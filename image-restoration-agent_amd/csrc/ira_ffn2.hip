@@ -72,6 +72,9 @@ IRA_DEV f32x8 sload8(const float* p) {
 }
 
 typedef float f32x16s __attribute__((ext_vector_type(16)));
+IRA_DEV float sload1(const float* p) {
+    return *(const __attribute__((address_space(4))) float*)(unsigned long long)p;
+}
 IRA_DEV f32x16 sload16(const float* p) {
     return *(const __attribute__((address_space(4))) f32x16*)(unsigned long long)p;
 }
@@ -400,6 +403,21 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
     // requested right behind the barrier its latency lay open once per interval (diagnostic build with constant weights: 7.22 -> 6.43 ms per
     // 40-tile launch).  They are requested one interval ahead instead - in slot 8, into the register set slot 7 has just finished with: nine
     // slots per interval, so the sets swap roles from one interval to the next: slot t of interval i uses set (t + i) & 1.
+    // ... and the unit's other eight lines are TOUCHED (one dword each) between the wait and the s_barrier of the interval's barrier: the loads
+    // fly while the wave sits in the barrier, whichever of the four waves that share the unit's octet arrives first pulls the lines into the
+    // scalar cache for all, and the per-slot requests of the next interval hit (7.69 -> 7.39 ms per 40-tile launch at C = 96; at C = 48,
+    // where an interval is half as long, 3.04 -> 3.07: not done there).  Ordinary loads into registers that stay reserved until slot 0's wait
+    // has passed (unit_touch_done): a scalar load the compiler does not know of would land in a register it has meanwhile given away.
+    constexpr bool TOUCH = C == 96;
+    float utch[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto unit_touch = [&](const float* wunit) {
+        if (DBG == 1 || !TOUCH) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) utch[k] = sload1(wunit + 16 * (k + 1));
+    };
+    auto unit_touch_done = [&]() {
+        if (TOUCH) asm volatile("" :: "s"(utch[0]), "s"(utch[1]), "s"(utch[2]), "s"(utch[3]), "s"(utch[4]), "s"(utch[5]), "s"(utch[6]), "s"(utch[7]));
+    };
     auto unit_w0 = [&](const float* wunit, int set) {
         if (DBG == 1) { for (int e = 0; e < 16; ++e) uw[set][e] = 0.01f * (e + 1); }
         else uw[set] = sload16(wunit);
@@ -537,6 +555,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
                 SLOTSTAMP(i);
                 IRA_WAIT_LGKM();
                 SLOTSTAMP(i);
+                if constexpr (t == 0) unit_touch_done();
                 IRA_PIN();
                 if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
                 if constexpr (t == 8 && DBG != 2 && DBG < 12) { if (i < NCH) unit_w0(dwu + (long)(i * 2 + uoc) * 144, sl ^ 1); }   // the next interval's slot 0
@@ -579,7 +598,10 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             if (un) unit_finish(i - 1);
             STAMP();
             if (pr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk i + 1's weights has landed (the P waves have no other vector-memory traffic)
-            lds_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (DBG != 2 && DBG < 12 && i < NCH) unit_touch(dwu + (long)(i * 2 + uoc) * 144);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             STAMP();
         };
         using I0 = IC<0>; using I1 = IC<1>;
@@ -617,6 +639,7 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
             SLOTSTAMP(i);
             IRA_WAIT_LGKM();
             SLOTSTAMP(i);
+            if constexpr (t == 0) unit_touch_done();
             IRA_PIN();
             if constexpr (un && t < 8) unit_request(hbase, wunit, IC<(t < 8 ? t + 1 : 8)>{}, sl ^ 1);
             if constexpr (t == 8 && DBG != 2 && DBG < 12) { if (un_ && i < NCH) unit_w0(dwu + (long)(i * 2 + uoc) * 144, sl ^ 1); }
@@ -636,7 +659,12 @@ __global__ __launch_bounds__(512) void k_ffn2(const float* __restrict__ x, float
         slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{}); slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{}); slot(IC<8>{});
         if (un) unit_finish(i - 1);
         STAMP();
-        if (un_) lds_barrier();
+        if (un_) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (DBG != 2 && DBG < 12 && i < NCH) unit_touch(dwu + (long)(i * 2 + uoc) * 144);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         STAMP();
     };
     unit_w0(dwu + (long)uoc * 144, 1);                      // chunk 0's unit runs in interval 1: set (0 + 1) & 1
